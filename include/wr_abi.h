@@ -1,0 +1,259 @@
+/*
+ * wr_abi.h -- C ABI of libwr_hip.so, the MI355X (gfx950) implementation of the
+ * per-frame render path of nullprop/wgpu-renderer.
+ *
+ * The reference has no FFI of its own: its frame orchestrator (src/core/state.rs)
+ * talks to wgpu::Device / wgpu::Queue.  Every entry point below replaces one kind of
+ * call the reference makes at that seam; the citation on each declaration names it.
+ * Payload structs are byte-identical to the #[repr(C)] structs the reference uploads
+ * with bytemuck, so a Rust host can pass `&self.camera_uniform as *const _` unchanged.
+ *
+ * Conventions
+ *   - return 0 (WR_OK) on success, a negative WrStatus on failure; wr_last_error()
+ *     gives a text for the last failure on that context.  Nothing throws or aborts.
+ *   - the caller owns every input pointer; the library copies during the call.
+ *   - one caller thread per context, calls are executed in order on one HIP stream
+ *     (the reference drives wgpu from the single winit event-loop thread,
+ *     src/core/window.rs:55-69, and wgpu queues execute in submission order).
+ *   - all matrices are column-major [[f32;4];4] exactly as cgmath/bytemuck lay them out.
+ */
+#ifndef WR_ABI_H
+#define WR_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ payload structs */
+
+/* src/core/model.rs:14-22 `ModelVertex` (56 B; offsets 0/12/20/32/44). */
+typedef struct WrModelVertex {
+    float position[3];
+    float tex_coords[2];
+    float normal[3];
+    float tangent[3];
+    float bitangent[3];
+} WrModelVertex;
+
+/* src/core/instance.rs:9-14 `InstanceRaw` (100 B): model 4x4 then normal 3x3. */
+typedef struct WrInstanceRaw {
+    float model[4][4];
+    float normal[3][3];
+} WrInstanceRaw;
+
+/* src/core/camera.rs:104-112 `CameraUniform` (224 B). */
+typedef struct WrCameraUniform {
+    float view[4][4];
+    float proj[4][4];
+    float inv_view_proj[4][4];
+    float position[4];
+    float planes[4]; /* near, far, width, height */
+} WrCameraUniform;
+
+/* src/core/light.rs:11-18 `LightUniform` (416 B). */
+typedef struct WrLightUniform {
+    float position[3];
+    uint32_t _padding;
+    float color[4]; /* rgb + intensity */
+    float matrices[6][4][4];
+} WrLightUniform;
+
+/* src/core/state.rs:21-28 `GlobalUniforms` (16 B).  light_matrix_index is ignored:
+ * the library loops over the six cube faces itself (state.rs:633-675). */
+typedef struct WrGlobalUniforms {
+    float time;
+    uint32_t light_matrix_index;
+    uint32_t use_shadowmaps;
+    uint32_t _padding;
+} WrGlobalUniforms;
+
+/* src/core/material.rs:13-18 `MaterialUniform` (16 B): metallic, roughness, 0, 0. */
+typedef struct WrMaterialUniform {
+    float factors[4];
+} WrMaterialUniform;
+
+/* ------------------------------------------------------------------ enums */
+
+typedef enum WrStatus {
+    WR_OK = 0,
+    WR_ERR_INVALID_ARGUMENT = -1,
+    WR_ERR_OUT_OF_MEMORY = -2,    /* window.rs:77 SurfaceError::OutOfMemory */
+    WR_ERR_DEVICE = -3,           /* a HIP call failed (window.rs:73 SurfaceError::Lost) */
+    WR_ERR_UNSUPPORTED = -4,
+    WR_ERR_CAPACITY = -5,         /* an internal list overflowed its capacity */
+    WR_ERR_NO_SCENE = -6
+} WrStatus;
+
+/* Which model a mesh / material / instance belongs to (state.rs:379-405: geom_model,
+ * fog_model, light_model). */
+typedef enum WrModel {
+    WR_MODEL_GEOMETRY = 0,
+    WR_MODEL_FOG_VOLUME = 1,
+    WR_MODEL_LIGHT_MARKER = 2
+} WrModel;
+
+/* Which passes of State::render run.  The reference has no run-time switch; its wasm32
+ * build is "no shadows, no fog" (state.rs:38,388,486,627,763) and native is all three. */
+enum {
+    WR_PASS_SHADOWS = 1u,     /* state.rs:633-675, six depth passes */
+    WR_PASS_FOG = 2u,         /* state.rs:763-804 */
+    WR_PASS_LIGHT_DEBUG = 4u, /* state.rs:728-759 */
+    WR_PASS_ALL = 7u
+};
+
+enum { WR_FORMAT_RGBA8_UNORM_SRGB = 0 };
+
+typedef struct WrConfig {
+    uint32_t width;           /* state.rs:104-108 surface size */
+    uint32_t height;
+    uint32_t shadow_map_size; /* state.rs:18 SHADOW_MAP_SIZE (2048); 0 selects 2048 */
+    uint32_t color_format;    /* state.rs:106 caps.formats[0]; only RGBA8 sRGB here */
+    int32_t device;           /* HIP device ordinal */
+    /* Screen-bin sharding across contexts: this context produces only the 64x64-pixel
+     * bins b (row-major bin index) with b % tile_world == tile_rank.  tile_world 0 or 1
+     * renders the whole frame. */
+    uint32_t tile_rank;
+    uint32_t tile_world;
+    /* hipStream_t to run on, or NULL for a library-owned stream. */
+    void* stream;
+} WrConfig;
+
+typedef struct WrContext WrContext;
+
+/* Per-frame counters and per-stage device times of the last wr_render_frame call, read
+ * after wr_sync.  Times are HIP-event milliseconds on the context's stream and are only
+ * recorded while wr_set_profiling(ctx, 1) is in effect.  No counterpart in the reference
+ * (timestamp_writes: None on every pass, state.rs:660,713,749,788). */
+typedef struct WrFrameStats {
+    float ms_shadow;   /* shadow vertex + setup + binning + raster, six faces */
+    float ms_geometry; /* geometry vertex + setup + binning + raster */
+    float ms_shade;    /* deferred PBS shading incl. PCF and ordered blending */
+    float ms_fog;      /* fog volume raster + march */
+    float ms_total;
+    uint32_t geometry_bin_items; /* (triangle, 64x64 bin) pairs the geometry rasteriser processed */
+    uint32_t shadow_bin_items;   /* same for the six shadow faces together */
+    uint64_t fog_fragments;      /* fog fragments that passed the depth test (counting mode only) */
+    uint64_t fog_noise_evals;    /* fog_noise evaluations executed (counting mode only) */
+    uint64_t shaded_fragments;   /* PBS fragments shaded (counting mode only) */
+    uint64_t replay_pixels;      /* pixels that took the ordered-blend path (counting mode only) */
+} WrFrameStats;
+
+/* ------------------------------------------------------------------ context */
+
+/* Replaces State::new's device/queue/surface/pipeline creation, state.rs:69-114,213-241,
+ * 435-504 (the four RenderPass pipelines become fixed kernels). */
+int wr_create(const WrConfig* config, WrContext** out_ctx);
+void wr_destroy(WrContext* ctx);
+
+/* Replaces State::resize, state.rs:575-587 (new colour target + geometry depth). */
+int wr_resize(WrContext* ctx, uint32_t width, uint32_t height);
+
+const char* wr_last_error(const WrContext* ctx);
+
+/* ------------------------------------------------------------------ scene upload (load time) */
+
+/* Replaces Texture::from_pixels -> queue.write_texture, texture.rs:74-116.  `srgb` != 0
+ * is Rgba8UnormSrgb (base colour, resources.rs:62), 0 is Rgba8Unorm (resources.rs:89,116).
+ * Texture ids are global to the context. */
+int wr_upload_texture(WrContext* ctx, const uint8_t* rgba8, uint32_t width, uint32_t height,
+                      int srgb, uint32_t* out_texture);
+
+/* Replaces Material::new, material.rs:21-87.  Material ids count from 0 per model in
+ * call order, like `materials.push` in resources.rs:121. */
+int wr_upload_material(WrContext* ctx, uint32_t model, uint32_t tex_base_color,
+                       uint32_t tex_normal, uint32_t tex_metallic_roughness,
+                       float metallic_factor, float roughness_factor, uint32_t* out_material);
+
+/* Replaces the vertex/index create_buffer_init of Mesh::from_gltf, mesh.rs:91-108.
+ * Call order is draw order (model.rs:147-156); it defines global triangle ids:
+ * id = (triangles of earlier meshes of the model) + local triangle index. */
+int wr_upload_mesh(WrContext* ctx, uint32_t model, const WrModelVertex* vertices,
+                   uint32_t vertex_count, const uint32_t* indices, uint32_t index_count,
+                   uint32_t material);
+
+/* Replaces the instance create_buffer_init calls, state.rs:413-433.  One instance per
+ * model (the reference draws 0..1 of each). */
+int wr_set_instances(WrContext* ctx, uint32_t model, const WrInstanceRaw* instances,
+                     uint32_t count);
+
+/* Drops every mesh, material and texture (no counterpart; the reference loads once). */
+int wr_clear_scene(WrContext* ctx);
+
+/* ------------------------------------------------------------------ per frame */
+
+/* Replaces the three queue.write_buffer calls of State::update (state.rs:603-607,619-623,
+ * 635-639) plus all of State::render (state.rs:630-809).  Asynchronous: work is enqueued
+ * on the context's stream.  `passes` is a mask of WR_PASS_*. */
+int wr_render_frame(WrContext* ctx, const WrCameraUniform* camera, const WrLightUniform* light,
+                    const WrGlobalUniforms* globals, uint32_t passes);
+
+/* Frame-parallel throughput mode: renders `count` camera poses under one light and one
+ * time value.  The six shadow passes run once and are reused unless
+ * `shadows_every_frame` != 0 (then every pose repeats them, as consecutive State::render
+ * calls would).  If `device_frames` is not NULL it must be device memory for
+ * count*width*height*4 bytes and receives every finished frame; otherwise only the last
+ * frame stays readable. */
+int wr_render_batch(WrContext* ctx, const WrCameraUniform* cameras, uint32_t count,
+                    const WrLightUniform* light, const WrGlobalUniforms* globals,
+                    uint32_t passes, int shadows_every_frame, void* device_frames);
+
+/* Blocks until the context's stream is idle (surface_texture.present(), state.rs:806,
+ * is the reference's end-of-frame point). */
+int wr_sync(WrContext* ctx);
+
+/* ------------------------------------------------------------------ results */
+
+/* Synchronous copies to host memory.  Colour is RGBA8 (sRGB-encoded), row-major, top row
+ * first: the surface texture of state.rs:678-681.  Depth is the geometry depth texture
+ * (state.rs:562-573).  Visibility is, per pixel, (triangle id << 3 | clip-fan index) of
+ * the fragment that owns the depth value, 0xFFFFFFFF where nothing was drawn; ids of the
+ * light marker continue after the geometry model's.  Shadow is the 6-layer depth array
+ * (state.rs:215-224), layer-major. */
+int wr_read_color(WrContext* ctx, uint8_t* dst, size_t bytes);
+int wr_read_depth(WrContext* ctx, float* dst, size_t bytes);
+int wr_read_visibility(WrContext* ctx, uint32_t* dst, size_t bytes);
+int wr_read_shadow_map(WrContext* ctx, float* dst, size_t bytes);
+
+/* Device address of the RGBA8 colour target, for collectives that gather tiles without a
+ * host round trip.  Valid until wr_resize / wr_destroy. */
+void* wr_color_device_ptr(WrContext* ctx);
+
+/* Copies the bins this context owns (see WrConfig.tile_rank) into `device_dst`, packed in
+ * ascending bin order as 64x64x4-byte blocks; returns the number of bins through
+ * `out_bins`.  wr_scatter_bins is the inverse on the gathering side: it writes `bins`
+ * packed blocks that belong to `rank` of `world` into this context's colour target. */
+int wr_pack_owned_bins(WrContext* ctx, void* device_dst, uint32_t* out_bins);
+int wr_scatter_bins(WrContext* ctx, const void* device_src, uint32_t rank, uint32_t world);
+
+int wr_set_profiling(WrContext* ctx, int enabled);
+/* enabled != 0 makes the next frames also count fragments / march steps with atomics
+ * (slower; never enable it inside a timed region). */
+int wr_set_counting(WrContext* ctx, int enabled);
+int wr_get_stats(WrContext* ctx, WrFrameStats* out);
+
+/* ------------------------------------------------------------------ host scene math
+ * The Rust host keeps these (src/core/camera.rs, light.rs, instance.rs); they are
+ * provided so that a C/C++/Python host produces the same uniform bytes. */
+
+/* camera.rs:56-76 get_view_matrix/get_vecs + camera.rs:25-33 + camera.rs:125-134. */
+void wr_camera_uniform_update(WrCameraUniform* out, const float position[3], float pitch_deg,
+                              float yaw_deg, float fovy_deg, uint32_t width, uint32_t height);
+/* light.rs:32-42 update_matrices: six perspective(90 deg,1,near,far) * look_to_rh. */
+void wr_light_update_matrices(WrLightUniform* light);
+/* state.rs:609-617 light animation + light.rs:32; color[3] (intensity) is left as is. */
+void wr_light_animate(WrLightUniform* light, float time_seconds);
+/* instance.rs:16-25 Instance::to_raw; rotation is a quaternion (w, x, y, z). */
+void wr_instance_to_raw(WrInstanceRaw* out, const float position[3], const float rotation_wxyz[4],
+                        const float scale[3]);
+/* camera.rs:78-101 Camera::update (fly controls).  pose = {x,y,z,pitch,yaw};
+ * input = {deltax, deltay, forward-backward, right-left, up-down}. */
+void wr_camera_fly_update(float pose[5], const float input[5], float speed, float sensitivity,
+                          float dt_seconds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WR_ABI_H */

@@ -1,0 +1,90 @@
+// Host-side unit access to the product's __host__ __device__ arithmetic (csrc/wr_device.h),
+// so that CPU-only tests can compare it bit for bit with the oracle before any GPU run.
+// Test infrastructure: exposes single functions only, no rendering path.
+#include <cstring>
+#include <cmath>
+#include "../../wgpu-renderer_amd/csrc/wr_device.h"
+using namespace wr;
+
+extern "C" {
+float hc_sin(float x) { return wr_sin(x); }
+float hc_value_noise(const float* p) { return value_noise(v3(p[0], p[1], p[2])); }
+float hc_fbm(const float* p) { return fbm(v3(p[0], p[1], p[2])); }
+float hc_fog_noise(const float* p, float time) {
+    FrameConsts fc; memset(&fc, 0, sizeof(fc));
+    fc.time = time; fc.drift_xy = time * 0.2f; fc.drift_z = wr_sin(time * 0.1f) * 0.5f;
+    return fog_noise(fc, v3(p[0], p[1], p[2]));
+}
+void hc_brdf(const float* n, const float* l, const float* v, const float* h, const float* a, float rough, float metal, float* out) {
+    V3 r = brdf(v3(n[0], n[1], n[2]), v3(l[0], l[1], l[2]), v3(v[0], v[1], v[2]), v3(h[0], h[1], h[2]), v3(a[0], a[1], a[2]), rough, metal);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void hc_ambient(const float* light, float dist, float sld, float* out) {
+    V3 r = sample_ambient_light(light, dist, sld);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+float hc_depth_to_linear(float d, float zn, float zf) { return depth_to_linear(d, zn, zf); }
+static float g_tables[768];
+static bool g_tables_ok = false;
+static void tables() {
+    if (g_tables_ok) return;
+    auto to_linear = [](double s) { return s <= 0.04045 ? s / 12.92 : pow((s + 0.055) / 1.055, 2.4); };
+    for (int c = 0; c < 256; ++c) {
+        g_tables[c] = (float)to_linear((double)c / 255.0);
+        g_tables[256 + c] = (float)c / 255.0f;
+        g_tables[512 + c] = c == 0 ? 0.0f : (float)to_linear(((double)c - 0.5) / 255.0);
+    }
+    g_tables_ok = true;
+}
+unsigned hc_srgb_encode(float x) { tables(); ColorTables ct{g_tables}; return srgb_encode(ct, x); }
+unsigned hc_blend_pack(unsigned dst, const float* src, int blend) { tables(); ColorTables ct{g_tables}; return blend_pack(ct, dst, V4{src[0], src[1], src[2], src[3]}, blend != 0); }
+
+// Same 28-word-per-sub-triangle layout as the oracle's wro_setup_triangle.
+int hc_setup_triangle(const float* clip, unsigned W, unsigned H, int shadow, unsigned* out, int max_subs) {
+    V4 c[3];
+    for (int k = 0; k < 3; ++k) c[k] = V4{clip[4 * k], clip[4 * k + 1], clip[4 * k + 2], clip[4 * k + 3]};
+    int cls = classify_triangle(c);
+    if (cls == 0) return 0;
+    ClipVert poly[10];
+    for (int k = 0; k < 3; ++k) {
+        poly[k].x = c[k].x; poly[k].y = c[k].y; poly[k].z = c[k].z; poly[k].w = c[k].w;
+        poly[k].b0 = k == 0; poly[k].b1 = k == 1; poly[k].b2 = k == 2;
+    }
+    int n = 3;
+    if (cls == 2) { n = clip_polygon(poly, 3); if (n < 3) return 0; }
+    int cnt = 0;
+    for (int i = 1; i + 1 < n && cnt < max_subs; ++i) {
+        ClipVert cv[3] = {poly[0], poly[i], poly[i + 1]};
+        Rec r; float beta[9];
+        if (!setup_sub(cv, (int)W, (int)H, shadow != 0, (unsigned)(i - 1), r, beta)) continue;
+        unsigned* w = out + (size_t)cnt * 28;
+        w[0] = r.X0; w[1] = r.Y0; w[2] = r.X1; w[3] = r.Y1; w[4] = r.X2; w[5] = r.Y2;
+        w[6] = f2u(r.z0); w[7] = f2u(r.dz1); w[8] = f2u(r.dz2); w[9] = f2u(r.inv2A);
+        if (shadow) {  // bias lives in iw0 for shadow records
+            w[10] = 0; w[11] = f2u(r.iw1); w[12] = f2u(r.iw2); w[13] = f2u(r.iw0);
+        } else {
+            w[10] = f2u(r.iw0); w[11] = f2u(r.iw1); w[12] = f2u(r.iw2); w[13] = 0;
+        }
+        w[14] = r.id & 7u; w[15] = r.bbmin & 0xffffu; w[16] = r.bbmin >> 16; w[17] = r.bbmax & 0xffffu; w[18] = r.bbmax >> 16;
+        for (int k = 0; k < 9; ++k) w[19 + k] = f2u(beta[k]);
+        ++cnt;
+    }
+    return cnt;
+}
+// coverage + depth + barycentrics of one pixel for the first sub-triangle: returns 1 if covered
+int hc_fragment(const float* clip, unsigned W, unsigned H, int px, int py, float* out_z, float* out_B) {
+    V4 c[3];
+    for (int k = 0; k < 3; ++k) c[k] = V4{clip[4 * k], clip[4 * k + 1], clip[4 * k + 2], clip[4 * k + 3]};
+    if (classify_triangle(c) != 1) return -1;
+    ClipVert cv[3];
+    for (int k = 0; k < 3; ++k) { cv[k].x = c[k].x; cv[k].y = c[k].y; cv[k].z = c[k].z; cv[k].w = c[k].w; cv[k].b0 = cv[k].b1 = cv[k].b2 = 0; }
+    Rec r;
+    if (!setup_sub(cv, (int)W, (int)H, false, 0, r, nullptr)) return -1;
+    Edges e; make_edges(r, e);
+    int64_t E[3]; edge_eval(e, px, py, E);
+    if (!edges_inside(e, E)) return 0;
+    *out_z = depth_at(r, E);
+    bary_at(r, nullptr, E, out_B);
+    return 1;
+}
+}

@@ -1,0 +1,129 @@
+"""ctypes binding of oracle/libwr_oracle.so, the CPU restatement used as the checker.
+Test infrastructure only: nothing under the product package imports this."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import wgpu_renderer_amd  # noqa: F401  (import shim)
+from wgpu_renderer_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "libwr_oracle.so")
+
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-C", ORACLE_DIR, "-s"], check=True)
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        L = C.CDLL(LIB)
+        P = C.c_void_p
+        L.wro_create.restype = P
+        L.wro_create.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+        L.wro_destroy.argtypes = [P]
+        L.wro_add_texture.restype = C.c_uint32
+        L.wro_add_texture.argtypes = [P, P, C.c_uint32, C.c_uint32, C.c_int]
+        L.wro_add_material.restype = C.c_uint32
+        L.wro_add_material.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float]
+        L.wro_add_mesh.argtypes = [P, C.c_uint32, P, C.c_uint32, P, C.c_uint32, C.c_uint32]
+        L.wro_set_instance.argtypes = [P, C.c_uint32, C.POINTER(abi.InstanceRaw)]
+        L.wro_render.restype = C.c_int
+        L.wro_render.argtypes = [P, C.POINTER(abi.CameraUniform), C.POINTER(abi.LightUniform), C.POINTER(abi.GlobalUniforms), C.c_uint32, C.c_int]
+        for n, t in (("wro_color", C.c_uint8), ("wro_depth", C.c_float), ("wro_visibility", C.c_uint32), ("wro_shadow", C.c_float)):
+            getattr(L, n).restype = C.POINTER(t)
+            getattr(L, n).argtypes = [P]
+        L.wro_counters.argtypes = [P, C.POINTER(C.c_uint64)]
+        L.wro_sin.restype = C.c_float
+        L.wro_sin.argtypes = [C.c_float]
+        for n in ("wro_rand", "wro_value_noise", "wro_fbm"):
+            getattr(L, n).restype = C.c_float
+            getattr(L, n).argtypes = [C.POINTER(C.c_float)]
+        L.wro_fog_noise.restype = C.c_float
+        L.wro_fog_noise.argtypes = [C.POINTER(C.c_float), C.c_float]
+        L.wro_depth_to_linear.restype = C.c_float
+        L.wro_depth_to_linear.argtypes = [C.c_float, C.c_float, C.c_float]
+        L.wro_srgb_encode.restype = C.c_uint8
+        L.wro_srgb_encode.argtypes = [C.c_float]
+        L.wro_srgb_decode.restype = C.c_float
+        L.wro_srgb_decode.argtypes = [C.c_uint8]
+        L.wro_brdf.argtypes = [C.POINTER(C.c_float)] * 5 + [C.c_float, C.c_float, C.POINTER(C.c_float)]
+        L.wro_ambient.argtypes = [C.POINTER(C.c_float), C.c_float, C.c_float, C.POINTER(C.c_float)]
+        L.wro_setup_triangle.restype = C.c_int
+        L.wro_setup_triangle.argtypes = [C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), C.c_int]
+        _lib = L
+    return _lib
+
+
+def f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+class Oracle:
+    """Same call sequence as abi.Renderer, executed by the CPU restatement."""
+
+    def __init__(self, width, height, shadow_map_size=2048):
+        self.L = lib()
+        self.h = self.L.wro_create(width, height, shadow_map_size)
+        self.width, self.height, self.shadow_map_size = width, height, shadow_map_size
+
+    def close(self):
+        if self.h:
+            self.L.wro_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload_scene(self, scene):
+        for rgba, srgb in scene.textures:
+            a = np.ascontiguousarray(rgba, np.uint8)
+            self.L.wro_add_texture(self.h, a.ctypes.data, a.shape[1], a.shape[0], int(srgb))
+        for mid, model, inst in ((0, scene.geometry, scene.geometry_instance), (1, scene.fog, scene.fog_instance), (2, scene.marker, None)):
+            if model is None:
+                continue
+            for m in model.materials:
+                self.L.wro_add_material(self.h, mid, m.base, m.normal, m.mr, m.metallic, m.roughness)
+            for mesh in model.meshes:
+                v = np.ascontiguousarray(mesh.vertices, np.float32)
+                i = np.ascontiguousarray(mesh.indices, np.uint32)
+                self.L.wro_add_mesh(self.h, mid, v.ctypes.data, v.shape[0], i.ctypes.data, i.size, mesh.material)
+            if inst is not None:
+                self.L.wro_set_instance(self.h, mid, C.byref(inst))
+
+    def render_frame(self, camera, light, globals_, passes, threads=8):
+        rc = self.L.wro_render(self.h, C.byref(camera), C.byref(light), C.byref(globals_), passes, threads)
+        if rc != 0:
+            raise RuntimeError(f"oracle render failed: {rc}")
+
+    def read_color(self):
+        return np.ctypeslib.as_array(self.L.wro_color(self.h), (self.height, self.width, 4)).copy()
+
+    def read_depth(self):
+        return np.ctypeslib.as_array(self.L.wro_depth(self.h), (self.height, self.width)).copy()
+
+    def read_visibility(self):
+        return np.ctypeslib.as_array(self.L.wro_visibility(self.h), (self.height, self.width)).copy()
+
+    def read_shadow_map(self):
+        s = self.shadow_map_size
+        return np.ctypeslib.as_array(self.L.wro_shadow(self.h), (6, s, s)).copy()
+
+    def counters(self):
+        out = (C.c_uint64 * 8)()
+        self.L.wro_counters(self.h, out)
+        return dict(fog_fragments=out[0], fog_noise_evals=out[1], shaded_fragments=out[2], blended_lt1=out[3],
+                    geometry_subtriangles=out[4], shadow_subtriangles=out[5])

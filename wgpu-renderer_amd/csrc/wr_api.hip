@@ -1,0 +1,759 @@
+// wr_api.hip -- C ABI of libwr_hip.so (declared in include/wr_abi.h): context, scene
+// upload, per-frame kernel sequence, read-back, and the host scene math that mirrors
+// src/core/camera.rs, light.rs and instance.rs.
+//
+// Device memory layout (all hipMalloc, owned by the context):
+//   scene   : per model SoA vertex streams (pos float4, uv float2, normal/tangent/bitangent
+//             float4), one merged u32 index buffer with mesh bases applied, one material id
+//             per triangle; all textures in one RGBA8 texel pool with a descriptor table.
+//   frame   : geometry vertex-stage outputs (5 float4 streams), shadow clip positions
+//             [6][V], triangle records + bin lists per raster target, visibility (u32) and
+//             depth (f32) buffers, RGBA8 colour, shadow array [6][S][S] f32.
+// There is no CPU rendering path: every entry point that produces pixels launches the
+// kernels of wr_kernels.h and fails with WR_ERR_DEVICE if HIP is unusable.
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/wr_abi.h"
+#include "wr_kernels.h"
+
+using namespace wr;
+
+static_assert(sizeof(WrModelVertex) == 56, "ModelVertex layout (model.rs:14-22)");
+static_assert(sizeof(WrInstanceRaw) == 100, "InstanceRaw layout (instance.rs:9-14)");
+static_assert(sizeof(WrCameraUniform) == 224, "CameraUniform layout (camera.rs:104-112)");
+static_assert(sizeof(WrLightUniform) == 416, "LightUniform layout (light.rs:11-18)");
+static_assert(sizeof(WrGlobalUniforms) == 16, "GlobalUniforms layout (state.rs:21-28)");
+static_assert(sizeof(WrMaterialUniform) == 16, "MaterialUniform layout (material.rs:13-18)");
+static_assert(sizeof(FrameConsts) < 3072, "FrameConsts must fit the kernel argument segment");
+
+namespace {
+
+struct ModelHost {
+    std::vector<WrModelVertex> verts;
+    std::vector<uint32_t> idx;
+    std::vector<uint32_t> tri_mat;
+    std::vector<MatDesc> mats;
+    WrInstanceRaw inst;
+    bool has_inst = false;
+};
+struct ModelDev {
+    float4* pos = nullptr;
+    float2* uv = nullptr;
+    float4 *nrm = nullptr, *tan = nullptr, *bit = nullptr;
+    uint32_t* idx = nullptr;
+    uint32_t* tri_mat = nullptr;
+    uint32_t nv = 0, ntris = 0;
+};
+struct TexHost { uint32_t w, h; int srgb; std::vector<uint8_t> px; };
+
+struct WsAlloc {
+    RasterWS ws{};
+    uint32_t* counters = nullptr;  // ovf_count | bin_count | bin_cursor, cleared every frame
+    size_t counters_bytes = 0;
+};
+
+}  // namespace
+
+struct WrContext {
+    WrConfig cfg{};
+    int W = 0, H = 0, S = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    ModelHost host[3];
+    std::vector<TexHost> tex_host;
+    bool scene_dirty = true;
+
+    ModelDev dev[3];
+    MatDesc* d_mats = nullptr;
+    TexDesc* d_tex = nullptr;
+    uint32_t* d_texels = nullptr;
+    float* d_tables = nullptr;
+
+    VertexOut vout{};
+    float4* d_shadow_clip = nullptr;
+    WsAlloc geom, shadow, fog;
+    uint32_t* d_vis = nullptr;
+    float* d_depth = nullptr;
+    uint32_t* d_color = nullptr;
+    float* d_shadow = nullptr;
+    unsigned long long* d_counters = nullptr;
+    uint32_t* d_err = nullptr;  // [0] error bits, [1] geometry bin items, [2] shadow bin items, [3] fog (unused)
+
+    bool profiling = false, counting = false;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+    WrFrameStats stats{};
+};
+
+namespace {
+
+int fail(WrContext* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+#define WR_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? WR_ERR_OUT_OF_MEMORY : WR_ERR_DEVICE, \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                  \
+    } while (0)
+
+template <class T>
+void dfree(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+void free_ws(WsAlloc& w) {
+    dfree(w.ws.recs); dfree(w.ws.betas); dfree(w.counters); dfree(w.ws.bin_offset); dfree(w.ws.bin_items);
+    w = WsAlloc();
+}
+
+int alloc_ws(WrContext* ctx, WsAlloc& w, uint32_t slots, uint32_t ovf_cap, uint32_t items_cap, int bins_x, int bins_y,
+             int layers, uint32_t* err, uint32_t* total_items) {
+    free_ws(w);
+    RasterWS& ws = w.ws;
+    ws.slots = slots; ws.ovf_cap = ovf_cap; ws.items_cap = items_cap;
+    ws.bins_x = bins_x; ws.bins_y = bins_y; ws.layers = layers;
+    ws.err = err; ws.total_items = total_items;
+    size_t nb = (size_t)bins_x * bins_y * layers;
+    WR_HIP(hipMalloc(&ws.recs, sizeof(Rec) * (size_t)layers * ((size_t)slots + ovf_cap)));
+    WR_HIP(hipMalloc(&ws.betas, sizeof(float) * 9 * (size_t)layers * ovf_cap + 64));
+    w.counters_bytes = sizeof(uint32_t) * ((size_t)layers + 2 * nb);
+    WR_HIP(hipMalloc(&w.counters, w.counters_bytes));
+    ws.ovf_count = w.counters;
+    ws.bin_count = w.counters + layers;
+    ws.bin_cursor = ws.bin_count + nb;
+    WR_HIP(hipMalloc(&ws.bin_offset, sizeof(uint32_t) * (nb + 1)));
+    WR_HIP(hipMalloc(&ws.bin_items, sizeof(uint32_t) * ((size_t)items_cap + 1)));
+    WR_HIP(hipMemset(w.counters, 0, w.counters_bytes));
+    return WR_OK;
+}
+
+void free_targets(WrContext* c) {
+    dfree(c->d_vis); dfree(c->d_depth); dfree(c->d_color);
+}
+void free_scene(WrContext* c) {
+    for (int m = 0; m < 3; ++m) {
+        ModelDev& d = c->dev[m];
+        dfree(d.pos); dfree(d.uv); dfree(d.nrm); dfree(d.tan); dfree(d.bit); dfree(d.idx); dfree(d.tri_mat);
+        d = ModelDev();
+    }
+    dfree(c->d_mats); dfree(c->d_tex); dfree(c->d_texels);
+    dfree(c->vout.clip); dfree(c->vout.v0); dfree(c->vout.v1); dfree(c->vout.v2); dfree(c->vout.v3);
+    dfree(c->d_shadow_clip);
+    free_ws(c->geom); free_ws(c->shadow); free_ws(c->fog);
+}
+
+int alloc_targets(WrContext* ctx) {
+    free_targets(ctx);
+    size_t n = (size_t)ctx->W * ctx->H;
+    WR_HIP(hipMalloc(&ctx->d_vis, n * 4));
+    WR_HIP(hipMalloc(&ctx->d_depth, n * 4));
+    WR_HIP(hipMalloc(&ctx->d_color, n * 4));
+    WR_HIP(hipMemset(ctx->d_color, 0, n * 4));
+    return WR_OK;
+}
+
+// (Re)builds every device buffer that depends on the uploaded scene or the target size.
+int build_scene(WrContext* ctx) {
+    WR_HIP(hipSetDevice(ctx->cfg.device));
+    WR_HIP(hipStreamSynchronize(ctx->stream));
+    free_scene(ctx);
+    for (int m = 0; m < 3; ++m) {
+        ModelHost& h = ctx->host[m];
+        ModelDev& d = ctx->dev[m];
+        d.nv = (uint32_t)h.verts.size();
+        d.ntris = (uint32_t)(h.idx.size() / 3);
+        if (d.nv == 0 || d.ntris == 0) continue;
+        std::vector<float4> pos(d.nv), nrm(d.nv), tan(d.nv), bit(d.nv);
+        std::vector<float2> uv(d.nv);
+        for (uint32_t i = 0; i < d.nv; ++i) {
+            const WrModelVertex& v = h.verts[i];
+            pos[i] = make_float4(v.position[0], v.position[1], v.position[2], 1.0f);
+            uv[i] = make_float2(v.tex_coords[0], v.tex_coords[1]);
+            nrm[i] = make_float4(v.normal[0], v.normal[1], v.normal[2], 0.0f);
+            tan[i] = make_float4(v.tangent[0], v.tangent[1], v.tangent[2], 0.0f);
+            bit[i] = make_float4(v.bitangent[0], v.bitangent[1], v.bitangent[2], 0.0f);
+        }
+        WR_HIP(hipMalloc(&d.pos, sizeof(float4) * d.nv));
+        WR_HIP(hipMalloc(&d.uv, sizeof(float2) * d.nv));
+        WR_HIP(hipMalloc(&d.nrm, sizeof(float4) * d.nv));
+        WR_HIP(hipMalloc(&d.tan, sizeof(float4) * d.nv));
+        WR_HIP(hipMalloc(&d.bit, sizeof(float4) * d.nv));
+        WR_HIP(hipMalloc(&d.idx, sizeof(uint32_t) * h.idx.size()));
+        WR_HIP(hipMalloc(&d.tri_mat, sizeof(uint32_t) * d.ntris));
+        WR_HIP(hipMemcpy(d.pos, pos.data(), sizeof(float4) * d.nv, hipMemcpyHostToDevice));
+        WR_HIP(hipMemcpy(d.uv, uv.data(), sizeof(float2) * d.nv, hipMemcpyHostToDevice));
+        WR_HIP(hipMemcpy(d.nrm, nrm.data(), sizeof(float4) * d.nv, hipMemcpyHostToDevice));
+        WR_HIP(hipMemcpy(d.tan, tan.data(), sizeof(float4) * d.nv, hipMemcpyHostToDevice));
+        WR_HIP(hipMemcpy(d.bit, bit.data(), sizeof(float4) * d.nv, hipMemcpyHostToDevice));
+        WR_HIP(hipMemcpy(d.idx, h.idx.data(), sizeof(uint32_t) * h.idx.size(), hipMemcpyHostToDevice));
+        WR_HIP(hipMemcpy(d.tri_mat, h.tri_mat.data(), sizeof(uint32_t) * d.ntris, hipMemcpyHostToDevice));
+    }
+    // textures: one texel pool
+    {
+        std::vector<TexDesc> descs;
+        size_t total = 0;
+        for (const TexHost& t : ctx->tex_host) {
+            descs.push_back(TexDesc{(uint32_t)total, t.w, t.h, (uint32_t)(t.srgb != 0)});
+            total += (size_t)t.w * t.h;
+        }
+        if (total >= 0xFFFFFFFFull) return fail(ctx, WR_ERR_UNSUPPORTED, "texture pool exceeds 2^32 texels");
+        WR_HIP(hipMalloc(&ctx->d_texels, std::max<size_t>(total, 1) * 4));
+        WR_HIP(hipMalloc(&ctx->d_tex, std::max<size_t>(descs.size(), 1) * sizeof(TexDesc)));
+        for (size_t i = 0; i < ctx->tex_host.size(); ++i)
+            WR_HIP(hipMemcpy(ctx->d_texels + descs[i].offset, ctx->tex_host[i].px.data(), ctx->tex_host[i].px.size(), hipMemcpyHostToDevice));
+        if (!descs.empty()) WR_HIP(hipMemcpy(ctx->d_tex, descs.data(), descs.size() * sizeof(TexDesc), hipMemcpyHostToDevice));
+    }
+    {
+        const std::vector<MatDesc>& mats = ctx->host[WR_MODEL_GEOMETRY].mats;
+        WR_HIP(hipMalloc(&ctx->d_mats, std::max<size_t>(mats.size(), 1) * sizeof(MatDesc)));
+        if (!mats.empty()) WR_HIP(hipMemcpy(ctx->d_mats, mats.data(), mats.size() * sizeof(MatDesc), hipMemcpyHostToDevice));
+    }
+    const uint32_t nvg = ctx->dev[WR_MODEL_GEOMETRY].nv, ntg = ctx->dev[WR_MODEL_GEOMETRY].ntris;
+    const uint32_t ntl = ctx->dev[WR_MODEL_LIGHT_MARKER].ntris, ntf = ctx->dev[WR_MODEL_FOG_VOLUME].ntris;
+    if ((uint64_t)ntg + ntl >= (1u << 29)) return fail(ctx, WR_ERR_UNSUPPORTED, "more than 2^29 triangles");
+    size_t nvs = std::max<uint32_t>(nvg, 1);
+    WR_HIP(hipMalloc(&ctx->vout.clip, sizeof(float4) * nvs));
+    WR_HIP(hipMalloc(&ctx->vout.v0, sizeof(float4) * nvs));
+    WR_HIP(hipMalloc(&ctx->vout.v1, sizeof(float4) * nvs));
+    WR_HIP(hipMalloc(&ctx->vout.v2, sizeof(float4) * nvs));
+    WR_HIP(hipMalloc(&ctx->vout.v3, sizeof(float4) * nvs));
+    WR_HIP(hipMalloc(&ctx->d_shadow_clip, sizeof(float4) * nvs * 6));
+    int rc;
+    {
+        uint32_t slots = ntg + ntl;
+        uint32_t ovf = slots / 2 + 8192;
+        int bx = (ctx->W + kBin - 1) / kBin, by = (ctx->H + kBin - 1) / kBin;
+        uint32_t items = 8u * (slots + ovf) + 64u * (uint32_t)(bx * by) + (1u << 20);
+        if ((rc = alloc_ws(ctx, ctx->geom, std::max(slots, 1u), ovf, items, bx, by, 1, ctx->d_err, ctx->d_err + 1)) != WR_OK) return rc;
+    }
+    {
+        uint32_t slots = std::max(ntg, 1u);
+        uint32_t ovf = slots / 4 + 8192;
+        int bs = (ctx->S + kBin - 1) / kBin;
+        uint32_t items = 6u * (4u * slots + 64u * (uint32_t)(bs * bs) + (1u << 18));
+        if ((rc = alloc_ws(ctx, ctx->shadow, slots, ovf, items, bs, bs, 6, ctx->d_err, ctx->d_err + 2)) != WR_OK) return rc;
+    }
+    {
+        uint32_t slots = std::max(ntf, 1u);
+        if ((rc = alloc_ws(ctx, ctx->fog, slots, slots * kMaxFan + 8, 8, 1, 1, 1, ctx->d_err, ctx->d_err + 3)) != WR_OK) return rc;
+    }
+    ctx->scene_dirty = false;
+    return WR_OK;
+}
+
+void build_tables(float* t) {
+    auto to_linear = [](double s) { return s <= 0.04045 ? s / 12.92 : pow((s + 0.055) / 1.055, 2.4); };
+    for (int c = 0; c < 256; ++c) {
+        t[c] = (float)to_linear((double)c / 255.0);
+        t[256 + c] = (float)c / 255.0f;
+        t[512 + c] = c == 0 ? 0.0f : (float)to_linear(((double)c - 0.5) / 255.0);
+    }
+}
+
+FrameConsts make_consts(const WrContext* ctx, const WrCameraUniform* cam, const WrLightUniform* light,
+                        const WrGlobalUniforms* glob) {
+    FrameConsts fc;
+    memset(&fc, 0, sizeof(fc));
+    mat4_mul_mat4(&cam->proj[0][0], &cam->view[0][0], fc.pv);
+    memcpy(fc.model_geom, ctx->host[WR_MODEL_GEOMETRY].inst.model, 64);
+    memcpy(fc.normal_geom, ctx->host[WR_MODEL_GEOMETRY].inst.normal, 36);
+    memcpy(fc.model_fog, ctx->host[WR_MODEL_FOG_VOLUME].inst.model, 64);
+    memcpy(fc.light_m, light->matrices, sizeof(fc.light_m));
+    for (int k = 0; k < 3; ++k) { fc.cam_pos[k] = cam->position[k]; fc.light_pos[k] = light->position[k]; }
+    for (int k = 0; k < 4; ++k) { fc.light_color[k] = light->color[k]; fc.planes[k] = cam->planes[k]; }
+    fc.time = glob->time;
+    fc.drift_xy = glob->time * 0.2f;
+    fc.drift_z = wr_sin(glob->time * 0.1f) * 0.5f;
+    fc.use_shadowmaps = glob->use_shadowmaps;
+    fc.W = ctx->W; fc.H = ctx->H; fc.S = ctx->S;
+    fc.tile_rank = (int)ctx->cfg.tile_rank;
+    fc.tile_world = (int)(ctx->cfg.tile_world ? ctx->cfg.tile_world : 1);
+    return fc;
+}
+
+dim3 grid1(uint32_t n, uint32_t layers = 1) { return dim3((n + 255u) / 256u, layers, 1); }
+
+int bin_and_raster(WrContext* ctx, WsAlloc& w, bool shadow, int tr, int tw) {
+    RasterWS& ws = w.ws;
+    uint32_t nrec = ws.slots + ws.ovf_cap;
+    hipLaunchKernelGGL(k_bin<false>, grid1(nrec, ws.layers), dim3(256), 0, ctx->stream, ws, tr, tw);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, ctx->stream, ws);
+    hipLaunchKernelGGL(k_bin<true>, grid1(nrec, ws.layers), dim3(256), 0, ctx->stream, ws, tr, tw);
+    dim3 g((uint32_t)(ws.bins_x * ws.bins_y), (uint32_t)ws.layers, 1);
+    if (shadow)
+        hipLaunchKernelGGL(k_raster<true>, g, dim3(256), 0, ctx->stream, ws, ctx->S, ctx->S, (uint32_t*)nullptr, ctx->d_shadow, 0, 1);
+    else
+        hipLaunchKernelGGL(k_raster<false>, g, dim3(256), 0, ctx->stream, ws, ctx->W, ctx->H, ctx->d_vis, ctx->d_depth, tr, tw);
+    return WR_OK;
+}
+
+int shadow_stage(WrContext* ctx, const FrameConsts& fc) {
+    const ModelDev& g = ctx->dev[WR_MODEL_GEOMETRY];
+    WR_HIP(hipMemsetAsync(ctx->shadow.counters, 0, ctx->shadow.counters_bytes, ctx->stream));
+    hipLaunchKernelGGL(k_vs_shadow, grid1(g.nv, 6), dim3(256), 0, ctx->stream, g.pos, g.nv, ctx->d_shadow_clip, fc);
+    hipLaunchKernelGGL(k_setup<true>, grid1(g.ntris, 6), dim3(256), 0, ctx->stream, ctx->d_shadow_clip, g.nv, g.idx, g.ntris,
+                       ctx->shadow.ws, ctx->S, ctx->S);
+    return bin_and_raster(ctx, ctx->shadow, true, 0, 1);
+}
+
+int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do_shadow) {
+    const ModelDev& g = ctx->dev[WR_MODEL_GEOMETRY];
+    const ModelDev& lm = ctx->dev[WR_MODEL_LIGHT_MARKER];
+    const ModelDev& fm = ctx->dev[WR_MODEL_FOG_VOLUME];
+    const bool prof = ctx->profiling;
+    int rc;
+    if (prof) WR_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    if (do_shadow && (passes & WR_PASS_SHADOWS))
+        if ((rc = shadow_stage(ctx, fc)) != WR_OK) return rc;
+    if (prof) WR_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+
+    // geometry + light marker -> visibility / depth
+    WR_HIP(hipMemsetAsync(ctx->geom.counters, 0, ctx->geom.counters_bytes, ctx->stream));
+    VertexIn vin{g.pos, g.uv, g.nrm, g.tan, g.bit, g.nv};
+    hipLaunchKernelGGL(k_vs_geometry, grid1(g.nv), dim3(256), 0, ctx->stream, vin, ctx->vout, fc);
+    hipLaunchKernelGGL(k_setup<false>, grid1(g.ntris, 1), dim3(256), 0, ctx->stream, ctx->vout.clip, g.nv, g.idx, g.ntris,
+                       ctx->geom.ws, ctx->W, ctx->H);
+    if (lm.ntris)
+        hipLaunchKernelGGL(k_setup_small, grid1(lm.ntris), dim3(256), 0, ctx->stream, lm.pos, lm.idx, lm.ntris, 0,
+                           (passes & WR_PASS_LIGHT_DEBUG) ? 1 : 0, g.ntris, ctx->geom.ws, fc);
+    if ((rc = bin_and_raster(ctx, ctx->geom, false, fc.tile_rank, fc.tile_world)) != WR_OK) return rc;
+    if (prof) WR_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+
+    ShadeArgs sa;
+    sa.fc = fc; sa.ws = ctx->geom.ws; sa.vis = ctx->d_vis; sa.depth = ctx->d_depth; sa.color = ctx->d_color;
+    sa.idx = g.idx; sa.tri_mat = g.tri_mat; sa.ntris_geom = g.ntris;
+    sa.v0 = ctx->vout.v0; sa.v1 = ctx->vout.v1; sa.v2 = ctx->vout.v2; sa.v3 = ctx->vout.v3;
+    sa.mats = ctx->d_mats; sa.tex = ctx->d_tex; sa.texels = ctx->d_texels; sa.tables = ctx->d_tables;
+    sa.shadow = ctx->d_shadow; sa.counters = ctx->d_counters;
+    dim3 pg((uint32_t)(ctx->W + 15) / 16, (uint32_t)(ctx->H + 15) / 16, 1);
+    if (ctx->counting) hipLaunchKernelGGL(k_shade<true>, pg, dim3(256), 0, ctx->stream, sa);
+    else hipLaunchKernelGGL(k_shade<false>, pg, dim3(256), 0, ctx->stream, sa);
+    if (prof) WR_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+
+    if ((passes & WR_PASS_FOG) && fm.ntris) {
+        WR_HIP(hipMemsetAsync(ctx->fog.counters, 0, ctx->fog.counters_bytes, ctx->stream));
+        hipLaunchKernelGGL(k_setup_small, grid1(fm.ntris), dim3(256), 0, ctx->stream, fm.pos, fm.idx, fm.ntris, 1, 1, 0u,
+                           ctx->fog.ws, fc);
+        FogArgs fa;
+        fa.fc = fc; fa.ws = ctx->fog.ws; fa.pos = fm.pos; fa.idx = fm.idx; fa.ntris = fm.ntris;
+        fa.depth = ctx->d_depth; fa.color = ctx->d_color; fa.shadow = ctx->d_shadow; fa.tables = ctx->d_tables;
+        fa.counters = ctx->d_counters;
+        if (ctx->counting) hipLaunchKernelGGL(k_fog<true>, pg, dim3(256), 0, ctx->stream, fa);
+        else hipLaunchKernelGGL(k_fog<false>, pg, dim3(256), 0, ctx->stream, fa);
+    }
+    if (prof) {
+        WR_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+        ctx->ev_valid = true;
+    }
+    WR_HIP(hipGetLastError());
+    return WR_OK;
+}
+
+int check_ready(WrContext* ctx, uint32_t passes) {
+    if (!ctx) return WR_ERR_INVALID_ARGUMENT;
+    if (ctx->host[WR_MODEL_GEOMETRY].idx.empty() || !ctx->host[WR_MODEL_GEOMETRY].has_inst)
+        return fail(ctx, WR_ERR_NO_SCENE, "geometry model needs at least one mesh and an instance");
+    if (ctx->host[WR_MODEL_GEOMETRY].mats.empty())
+        return fail(ctx, WR_ERR_NO_SCENE, "geometry model has no material");
+    if ((passes & WR_PASS_FOG) && (ctx->host[WR_MODEL_FOG_VOLUME].idx.empty() || !ctx->host[WR_MODEL_FOG_VOLUME].has_inst))
+        return fail(ctx, WR_ERR_NO_SCENE, "fog pass needs the fog-volume model and its instance");
+    if ((passes & WR_PASS_LIGHT_DEBUG) && ctx->host[WR_MODEL_LIGHT_MARKER].idx.empty())
+        return fail(ctx, WR_ERR_NO_SCENE, "light-debug pass needs the light-marker model");
+    WR_HIP(hipSetDevice(ctx->cfg.device));
+    if (ctx->scene_dirty) return build_scene(ctx);
+    return WR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wr_create(const WrConfig* config, WrContext** out_ctx) {
+    if (!config || !out_ctx) return WR_ERR_INVALID_ARGUMENT;
+    *out_ctx = nullptr;
+    if (config->width == 0 || config->height == 0 || config->width > 7168 || config->height > 7168) return WR_ERR_INVALID_ARGUMENT;
+    if (config->color_format != WR_FORMAT_RGBA8_UNORM_SRGB) return WR_ERR_UNSUPPORTED;
+    uint32_t S = config->shadow_map_size ? config->shadow_map_size : 2048u;
+    if (S > 7168) return WR_ERR_INVALID_ARGUMENT;
+    if (config->tile_world > 1 && config->tile_rank >= config->tile_world) return WR_ERR_INVALID_ARGUMENT;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return WR_ERR_DEVICE;
+    if (config->device < 0 || config->device >= ndev) return WR_ERR_INVALID_ARGUMENT;
+    if (hipSetDevice(config->device) != hipSuccess) return WR_ERR_DEVICE;
+    WrContext* ctx = new WrContext();
+    ctx->cfg = *config;
+    ctx->W = (int)config->width; ctx->H = (int)config->height; ctx->S = (int)S;
+    int rc = WR_OK;
+    auto body = [&]() -> int {
+        if (config->stream) ctx->stream = (hipStream_t)config->stream;
+        else { WR_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
+        for (int i = 0; i < 5; ++i) WR_HIP(hipEventCreate(&ctx->ev[i]));
+        float tables[768];
+        build_tables(tables);
+        WR_HIP(hipMalloc(&ctx->d_tables, sizeof(tables)));
+        WR_HIP(hipMemcpy(ctx->d_tables, tables, sizeof(tables), hipMemcpyHostToDevice));
+        WR_HIP(hipMalloc(&ctx->d_counters, 8 * sizeof(unsigned long long)));
+        WR_HIP(hipMemset(ctx->d_counters, 0, 8 * sizeof(unsigned long long)));
+        WR_HIP(hipMalloc(&ctx->d_err, 4 * sizeof(uint32_t)));
+        WR_HIP(hipMemset(ctx->d_err, 0, 4 * sizeof(uint32_t)));
+        size_t ns = (size_t)6 * S * S;
+        WR_HIP(hipMalloc(&ctx->d_shadow, ns * 4));
+        hipLaunchKernelGGL(k_fill_f32, dim3((uint32_t)((ns + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_shadow, ns, 1.0f);
+        WR_HIP(hipStreamSynchronize(ctx->stream));
+        return alloc_targets(ctx);
+    };
+    rc = body();
+    if (rc != WR_OK) { wr_destroy(ctx); return rc; }
+    *out_ctx = ctx;
+    return WR_OK;
+}
+
+void wr_destroy(WrContext* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->cfg.device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_scene(ctx);
+    free_targets(ctx);
+    dfree(ctx->d_tables); dfree(ctx->d_counters); dfree(ctx->d_err); dfree(ctx->d_shadow);
+    for (int i = 0; i < 5; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int wr_resize(WrContext* ctx, uint32_t width, uint32_t height) {
+    if (!ctx) return WR_ERR_INVALID_ARGUMENT;
+    if (width == 0 || height == 0) return WR_OK;  // state.rs:576 ignores empty sizes
+    if (width > 7168 || height > 7168) return fail(ctx, WR_ERR_INVALID_ARGUMENT, "target larger than 7168");
+    WR_HIP(hipSetDevice(ctx->cfg.device));
+    WR_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->W = (int)width; ctx->H = (int)height;
+    ctx->cfg.width = width; ctx->cfg.height = height;
+    ctx->scene_dirty = true;
+    return alloc_targets(ctx);
+}
+
+const char* wr_last_error(const WrContext* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int wr_upload_texture(WrContext* ctx, const uint8_t* rgba8, uint32_t width, uint32_t height, int srgb, uint32_t* out_texture) {
+    if (!ctx || !rgba8 || width == 0 || height == 0) return fail(ctx, WR_ERR_INVALID_ARGUMENT, "bad texture");
+    TexHost t;
+    t.w = width; t.h = height; t.srgb = srgb;
+    t.px.assign(rgba8, rgba8 + (size_t)width * height * 4);
+    ctx->tex_host.push_back(std::move(t));
+    if (out_texture) *out_texture = (uint32_t)ctx->tex_host.size() - 1;
+    ctx->scene_dirty = true;
+    return WR_OK;
+}
+
+int wr_upload_material(WrContext* ctx, uint32_t model, uint32_t tb, uint32_t tn, uint32_t tmr, float metallic, float roughness,
+                       uint32_t* out_material) {
+    if (!ctx || model > 2) return fail(ctx, WR_ERR_INVALID_ARGUMENT, "bad model");
+    size_t nt = ctx->tex_host.size();
+    if (tb >= nt || tn >= nt || tmr >= nt) return fail(ctx, WR_ERR_INVALID_ARGUMENT, "material names an unknown texture");
+    MatDesc m{tb, tn, tmr, metallic, roughness, 0, 0, 0};
+    ctx->host[model].mats.push_back(m);
+    if (out_material) *out_material = (uint32_t)ctx->host[model].mats.size() - 1;
+    ctx->scene_dirty = true;
+    return WR_OK;
+}
+
+int wr_upload_mesh(WrContext* ctx, uint32_t model, const WrModelVertex* vertices, uint32_t vertex_count,
+                   const uint32_t* indices, uint32_t index_count, uint32_t material) {
+    if (!ctx || model > 2 || !vertices || !indices) return fail(ctx, WR_ERR_INVALID_ARGUMENT, "bad mesh");
+    ModelHost& h = ctx->host[model];
+    if (model == WR_MODEL_GEOMETRY && material >= h.mats.size())
+        return fail(ctx, WR_ERR_INVALID_ARGUMENT, "mesh names an unknown material");
+    for (uint32_t i = 0; i < index_count; ++i)
+        if (indices[i] >= vertex_count) return fail(ctx, WR_ERR_INVALID_ARGUMENT, "index out of range");
+    uint32_t base = (uint32_t)h.verts.size();
+    h.verts.insert(h.verts.end(), vertices, vertices + vertex_count);
+    for (uint32_t i = 0; i + 2 < index_count; i += 3) {  // draw_indexed on a TriangleList ignores a partial last triangle
+        h.idx.push_back(base + indices[i]);
+        h.idx.push_back(base + indices[i + 1]);
+        h.idx.push_back(base + indices[i + 2]);
+        h.tri_mat.push_back(material);
+    }
+    ctx->scene_dirty = true;
+    return WR_OK;
+}
+
+int wr_set_instances(WrContext* ctx, uint32_t model, const WrInstanceRaw* instances, uint32_t count) {
+    if (!ctx || model > 2 || !instances) return fail(ctx, WR_ERR_INVALID_ARGUMENT, "bad instances");
+    if (count != 1) return fail(ctx, WR_ERR_UNSUPPORTED, "exactly one instance per model is supported");
+    ctx->host[model].inst = instances[0];
+    ctx->host[model].has_inst = true;
+    return WR_OK;
+}
+
+int wr_clear_scene(WrContext* ctx) {
+    if (!ctx) return WR_ERR_INVALID_ARGUMENT;
+    for (int m = 0; m < 3; ++m) ctx->host[m] = ModelHost();
+    ctx->tex_host.clear();
+    ctx->scene_dirty = true;
+    return WR_OK;
+}
+
+int wr_render_frame(WrContext* ctx, const WrCameraUniform* camera, const WrLightUniform* light,
+                    const WrGlobalUniforms* globals, uint32_t passes) {
+    if (!ctx || !camera || !light || !globals) return fail(ctx, WR_ERR_INVALID_ARGUMENT, "null uniform");
+    int rc = check_ready(ctx, passes);
+    if (rc != WR_OK) return rc;
+    if (ctx->counting) WR_HIP(hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    FrameConsts fc = make_consts(ctx, camera, light, globals);
+    return frame_stages(ctx, fc, passes, true);
+}
+
+int wr_render_batch(WrContext* ctx, const WrCameraUniform* cameras, uint32_t count, const WrLightUniform* light,
+                    const WrGlobalUniforms* globals, uint32_t passes, int shadows_every_frame, void* device_frames) {
+    if (!ctx || !cameras || !light || !globals) return fail(ctx, WR_ERR_INVALID_ARGUMENT, "null uniform");
+    int rc = check_ready(ctx, passes);
+    if (rc != WR_OK) return rc;
+    if (ctx->counting) WR_HIP(hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    size_t frame_bytes = (size_t)ctx->W * ctx->H * 4;
+    for (uint32_t i = 0; i < count; ++i) {
+        FrameConsts fc = make_consts(ctx, &cameras[i], light, globals);
+        if ((rc = frame_stages(ctx, fc, passes, shadows_every_frame || i == 0)) != WR_OK) return rc;
+        if (device_frames)
+            WR_HIP(hipMemcpyAsync((uint8_t*)device_frames + (size_t)i * frame_bytes, ctx->d_color, frame_bytes,
+                                  hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return WR_OK;
+}
+
+int wr_sync(WrContext* ctx) {
+    if (!ctx) return WR_ERR_INVALID_ARGUMENT;
+    WR_HIP(hipSetDevice(ctx->cfg.device));
+    WR_HIP(hipStreamSynchronize(ctx->stream));
+    uint32_t e[4] = {0, 0, 0, 0};
+    WR_HIP(hipMemcpy(e, ctx->d_err, sizeof(e), hipMemcpyDeviceToHost));
+    ctx->stats.geometry_bin_items = e[1];
+    ctx->stats.shadow_bin_items = e[2];
+    if (e[0]) {
+        WR_HIP(hipMemset(ctx->d_err, 0, sizeof(uint32_t)));
+        return fail(ctx, WR_ERR_CAPACITY,
+                    (e[0] & kErrClipOverflow) ? "clipped-triangle record capacity exceeded" : "bin item capacity exceeded");
+    }
+    return WR_OK;
+}
+
+static int read_back(WrContext* ctx, void* dst, size_t bytes, const void* src, size_t need) {
+    if (!ctx || !dst) return fail(ctx, WR_ERR_INVALID_ARGUMENT, "null destination");
+    if (bytes < need) return fail(ctx, WR_ERR_INVALID_ARGUMENT, "destination too small");
+    int rc = wr_sync(ctx);
+    if (rc != WR_OK) return rc;
+    WR_HIP(hipMemcpy(dst, src, need, hipMemcpyDeviceToHost));
+    return WR_OK;
+}
+int wr_read_color(WrContext* ctx, uint8_t* dst, size_t bytes) {
+    return read_back(ctx, dst, bytes, ctx ? ctx->d_color : nullptr, ctx ? (size_t)ctx->W * ctx->H * 4 : 0);
+}
+int wr_read_depth(WrContext* ctx, float* dst, size_t bytes) {
+    return read_back(ctx, dst, bytes, ctx ? ctx->d_depth : nullptr, ctx ? (size_t)ctx->W * ctx->H * 4 : 0);
+}
+int wr_read_visibility(WrContext* ctx, uint32_t* dst, size_t bytes) {
+    return read_back(ctx, dst, bytes, ctx ? ctx->d_vis : nullptr, ctx ? (size_t)ctx->W * ctx->H * 4 : 0);
+}
+int wr_read_shadow_map(WrContext* ctx, float* dst, size_t bytes) {
+    return read_back(ctx, dst, bytes, ctx ? ctx->d_shadow : nullptr, ctx ? (size_t)6 * ctx->S * ctx->S * 4 : 0);
+}
+
+void* wr_color_device_ptr(WrContext* ctx) { return ctx ? ctx->d_color : nullptr; }
+
+int wr_pack_owned_bins(WrContext* ctx, void* device_dst, uint32_t* out_bins) {
+    if (!ctx || !device_dst) return fail(ctx, WR_ERR_INVALID_ARGUMENT, "null destination");
+    WR_HIP(hipSetDevice(ctx->cfg.device));
+    int bx = (ctx->W + kBin - 1) / kBin, by = (ctx->H + kBin - 1) / kBin, nb = bx * by;
+    int world = (int)(ctx->cfg.tile_world ? ctx->cfg.tile_world : 1), rank = (int)ctx->cfg.tile_rank;
+    int owned = (nb - rank + world - 1) / world;
+    if (out_bins) *out_bins = (uint32_t)owned;
+    if (owned > 0)
+        hipLaunchKernelGGL(k_pack_bins, dim3((uint32_t)owned), dim3(256), 0, ctx->stream, ctx->d_color, (uint32_t*)device_dst,
+                           ctx->W, ctx->H, bx, nb, rank, world, 1);
+    WR_HIP(hipGetLastError());
+    return WR_OK;
+}
+
+int wr_scatter_bins(WrContext* ctx, const void* device_src, uint32_t rank, uint32_t world) {
+    if (!ctx || !device_src || world == 0 || rank >= world) return fail(ctx, WR_ERR_INVALID_ARGUMENT, "bad scatter arguments");
+    WR_HIP(hipSetDevice(ctx->cfg.device));
+    int bx = (ctx->W + kBin - 1) / kBin, by = (ctx->H + kBin - 1) / kBin, nb = bx * by;
+    int owned = (nb - (int)rank + (int)world - 1) / (int)world;
+    if (owned > 0)
+        hipLaunchKernelGGL(k_pack_bins, dim3((uint32_t)owned), dim3(256), 0, ctx->stream, ctx->d_color,
+                           (uint32_t*)const_cast<void*>(device_src), ctx->W, ctx->H, bx, nb, (int)rank, (int)world, 0);
+    WR_HIP(hipGetLastError());
+    return WR_OK;
+}
+
+int wr_set_profiling(WrContext* ctx, int enabled) {
+    if (!ctx) return WR_ERR_INVALID_ARGUMENT;
+    ctx->profiling = enabled != 0;
+    ctx->ev_valid = false;
+    return WR_OK;
+}
+int wr_set_counting(WrContext* ctx, int enabled) {
+    if (!ctx) return WR_ERR_INVALID_ARGUMENT;
+    ctx->counting = enabled != 0;
+    return WR_OK;
+}
+
+int wr_get_stats(WrContext* ctx, WrFrameStats* out) {
+    if (!ctx || !out) return WR_ERR_INVALID_ARGUMENT;
+    int rc = wr_sync(ctx);
+    if (rc != WR_OK) return rc;
+    if (ctx->ev_valid) {
+        float ms[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 4; ++i) WR_HIP(hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]));
+        ctx->stats.ms_shadow = ms[0]; ctx->stats.ms_geometry = ms[1]; ctx->stats.ms_shade = ms[2]; ctx->stats.ms_fog = ms[3];
+        ctx->stats.ms_total = ms[0] + ms[1] + ms[2] + ms[3];
+    }
+    unsigned long long c[8];
+    WR_HIP(hipMemcpy(c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    ctx->stats.fog_fragments = c[0]; ctx->stats.fog_noise_evals = c[1];
+    ctx->stats.shaded_fragments = c[2]; ctx->stats.replay_pixels = c[3];
+    *out = ctx->stats;
+    return WR_OK;
+}
+
+// ----------------------------------------------------------------------------- host scene math
+
+static void look_to_rh(const float eye[3], const float dir[3], const float up[3], float m[4][4]) {
+    // cgmath Matrix4::look_to_rh: f = normalize(dir), s = normalize(f x up), u = s x f
+    float fl = 1.0f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+    float f[3] = {dir[0] * fl, dir[1] * fl, dir[2] * fl};
+    float s[3] = {f[1] * up[2] - f[2] * up[1], f[2] * up[0] - f[0] * up[2], f[0] * up[1] - f[1] * up[0]};
+    float sl = 1.0f / sqrtf(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]);
+    s[0] *= sl; s[1] *= sl; s[2] *= sl;
+    float u[3] = {s[1] * f[2] - s[2] * f[1], s[2] * f[0] - s[0] * f[2], s[0] * f[1] - s[1] * f[0]};
+    m[0][0] = s[0]; m[0][1] = u[0]; m[0][2] = -f[0]; m[0][3] = 0.0f;
+    m[1][0] = s[1]; m[1][1] = u[1]; m[1][2] = -f[1]; m[1][3] = 0.0f;
+    m[2][0] = s[2]; m[2][1] = u[2]; m[2][2] = -f[2]; m[2][3] = 0.0f;
+    m[3][0] = -(eye[0] * s[0] + eye[1] * s[1] + eye[2] * s[2]);
+    m[3][1] = -(eye[0] * u[0] + eye[1] * u[1] + eye[2] * u[2]);
+    m[3][2] = eye[0] * f[0] + eye[1] * f[1] + eye[2] * f[2];
+    m[3][3] = 1.0f;
+}
+
+static void perspective(float fovy_deg, float aspect, float zn, float zf, float m[4][4]) {
+    // cgmath::perspective (GL-style clip z in [-w, w]); Deg -> Rad multiplies by f32(pi/180)
+    float rad = fovy_deg * (float)(3.14159265358979323846 / 180.0);
+    float f = 1.0f / tanf(rad / 2.0f);
+    memset(m, 0, 64);
+    m[0][0] = f / aspect;
+    m[1][1] = f;
+    m[2][2] = (zf + zn) / (zn - zf);
+    m[2][3] = -1.0f;
+    m[3][2] = (2.0f * zf * zn) / (zn - zf);
+}
+
+static bool invert4(const float* a, float* out) {
+    double m[4][8];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) { m[r][c] = a[4 * c + r]; m[r][4 + c] = r == c ? 1.0 : 0.0; }
+    for (int i = 0; i < 4; ++i) {
+        int p = i;
+        for (int r = i + 1; r < 4; ++r) if (fabs(m[r][i]) > fabs(m[p][i])) p = r;
+        if (m[p][i] == 0.0) return false;
+        for (int c = 0; c < 8; ++c) std::swap(m[i][c], m[p][c]);
+        double inv = 1.0 / m[i][i];
+        for (int c = 0; c < 8; ++c) m[i][c] *= inv;
+        for (int r = 0; r < 4; ++r) if (r != i) { double f = m[r][i]; for (int c = 0; c < 8; ++c) m[r][c] -= f * m[i][c]; }
+    }
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) out[4 * c + r] = (float)m[r][4 + c];
+    return true;
+}
+
+static const float kNear = 1.0f, kFar = 3000.0f;  // camera.rs:8-9
+
+void wr_camera_uniform_update(WrCameraUniform* out, const float position[3], float pitch_deg, float yaw_deg,
+                              float fovy_deg, uint32_t width, uint32_t height) {
+    const float d2r = (float)(3.14159265358979323846 / 180.0);
+    float ys = sinf(yaw_deg * d2r), yc = cosf(yaw_deg * d2r);
+    float ps = sinf(pitch_deg * d2r), pc = cosf(pitch_deg * d2r);
+    float fwd[3] = {pc * yc, ps, pc * ys};
+    float fl = 1.0f / sqrtf(fwd[0] * fwd[0] + fwd[1] * fwd[1] + fwd[2] * fwd[2]);
+    fwd[0] *= fl; fwd[1] *= fl; fwd[2] *= fl;
+    float right[3] = {-ys, 0.0f, yc};
+    float rl = 1.0f / sqrtf(right[0] * right[0] + right[1] * right[1] + right[2] * right[2]);
+    right[0] *= rl; right[1] *= rl; right[2] *= rl;
+    float up[3] = {right[1] * fwd[2] - right[2] * fwd[1], right[2] * fwd[0] - right[0] * fwd[2], right[0] * fwd[1] - right[1] * fwd[0]};
+    look_to_rh(position, fwd, up, out->view);
+    perspective(fovy_deg, (float)width / (float)height, kNear, kFar, out->proj);
+    float pv[16];
+    mat4_mul_mat4(&out->proj[0][0], &out->view[0][0], pv);
+    if (!invert4(pv, &out->inv_view_proj[0][0])) memset(out->inv_view_proj, 0, 64);
+    out->position[0] = position[0]; out->position[1] = position[1]; out->position[2] = position[2]; out->position[3] = 1.0f;
+    out->planes[0] = kNear; out->planes[1] = kFar; out->planes[2] = (float)width; out->planes[3] = (float)height;
+}
+
+void wr_light_update_matrices(WrLightUniform* light) {
+    float proj[4][4];
+    perspective(90.0f, 1.0f, kNear, kFar, proj);
+    static const float dirs[6][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+    static const float ups[6][3] = {{0, 1, 0}, {0, 1, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, 1, 0}};
+    for (int i = 0; i < 6; ++i) {
+        float view[4][4];
+        look_to_rh(light->position, dirs[i], ups[i], view);
+        mat4_mul_mat4(&proj[0][0], &view[0][0], &light->matrices[i][0][0]);
+    }
+}
+
+void wr_light_animate(WrLightUniform* light, float t) {
+    light->position[0] = sinf(t * 0.5f) * 500.0f;
+    light->position[1] = 250.0f + sinf(t * 0.3f) * 200.0f;
+    light->position[2] = sinf(t * 0.8f) * 100.0f;
+    wr_light_update_matrices(light);
+    light->color[0] = fabsf(sinf(t * 1.0f));
+    light->color[1] = fabsf(sinf(t * 0.6f));
+    light->color[2] = fabsf(sinf(t * 0.4f));
+}
+
+void wr_instance_to_raw(WrInstanceRaw* out, const float position[3], const float q[4], const float scale[3]) {
+    // cgmath Matrix3::from(Quaternion{s, v})
+    float s = q[0], x = q[1], y = q[2], z = q[3];
+    float x2 = x + x, y2 = y + y, z2 = z + z;
+    float xx2 = x2 * x, xy2 = x2 * y, xz2 = x2 * z, yy2 = y2 * y, yz2 = y2 * z, zz2 = z2 * z;
+    float sy2 = y2 * s, sz2 = z2 * s, sx2 = x2 * s;
+    float r[3][3] = {{1.0f - yy2 - zz2, xy2 + sz2, xz2 - sy2}, {xy2 - sz2, 1.0f - xx2 - zz2, yz2 + sx2}, {xz2 + sy2, yz2 - sx2, 1.0f - xx2 - yy2}};
+    for (int c = 0; c < 3; ++c) {
+        for (int rr = 0; rr < 3; ++rr) { out->normal[c][rr] = r[c][rr]; out->model[c][rr] = scale[rr] * r[c][rr]; }
+        out->model[c][3] = 0.0f;
+    }
+    out->model[3][0] = position[0]; out->model[3][1] = position[1]; out->model[3][2] = position[2]; out->model[3][3] = 1.0f;
+}
+
+void wr_camera_fly_update(float pose[5], const float in[5], float speed, float sensitivity, float dt) {
+    float pitch = pose[3] - in[1] * sensitivity * 0.022f;
+    pitch = pitch < -89.0f ? -89.0f : (pitch > 89.0f ? 89.0f : pitch);
+    float yaw = pose[4] + in[0] * sensitivity * 0.022f;
+    yaw = fmodf(yaw, 360.0f);
+    if (yaw < 0.0f) yaw += 360.0f;
+    const float d2r = (float)(3.14159265358979323846 / 180.0);
+    float ys = sinf(yaw * d2r), yc = cosf(yaw * d2r), ps = sinf(pitch * d2r), pc = cosf(pitch * d2r);
+    float fwd[3] = {pc * yc, ps, pc * ys};
+    float fl = 1.0f / sqrtf(fwd[0] * fwd[0] + fwd[1] * fwd[1] + fwd[2] * fwd[2]);
+    fwd[0] *= fl; fwd[1] *= fl; fwd[2] *= fl;
+    float right[3] = {-ys, 0.0f, yc};
+    float up[3] = {right[1] * fwd[2] - right[2] * fwd[1], right[2] * fwd[0] - right[0] * fwd[2], right[0] * fwd[1] - right[1] * fwd[0]};
+    for (int k = 0; k < 3; ++k) {
+        pose[k] += fwd[k] * in[2] * speed * dt;
+        pose[k] += right[k] * in[3] * speed * dt;
+        pose[k] += up[k] * in[4] * speed * dt;
+    }
+    pose[3] = pitch; pose[4] = yaw;
+}
+
+}  // extern "C"

@@ -1,0 +1,578 @@
+// wr_kernels.h -- gfx950 kernels of the render path.
+//
+// Frame structure (one HIP stream, kernels in this order):
+//   shadow   : k_vs_shadow -> k_setup<true> -> k_bin<count> -> k_scan -> k_bin<fill>
+//              -> k_raster<true>            (6 cube faces as grid.y "layers")
+//   geometry : k_vs_geometry -> k_setup<false> (+ k_setup_small for the light marker)
+//              -> k_bin/k_scan/k_bin -> k_raster<false>   (visibility + depth buffers)
+//   shade    : k_shade                      (deferred pbr.wgsl fragment stage + blending)
+//   fog      : k_setup_small(fog) -> k_fog  (fog.wgsl fragment stage + blending)
+//
+// The rasteriser is tile-binned: the target is cut into 64x64-pixel bins, every set-up
+// triangle is appended to the list of each bin it can touch, and one 256-thread workgroup
+// per bin resolves visibility in an LDS tile (64-bit keys: depth bits << 32 | triangle id,
+// combined with LDS atomic-min), then writes the tile out once with coalesced stores.
+// Within a workgroup a wavefront takes one triangle at a time and its 64 lanes test one
+// 8x8 pixel block per step, so the triangle record is wave-uniform (scalar loads).
+#pragma once
+
+#include "wr_device.h"
+
+namespace wr {
+
+struct RasterWS {
+    Rec* recs;            // [layers][slots + ovf_cap]
+    float* betas;         // [layers][ovf_cap][9] clip weights of records born in the clipper
+    uint32_t* ovf_count;  // [layers]
+    uint32_t* bin_count;  // [layers * bins]
+    uint32_t* bin_cursor; // [layers * bins]
+    uint32_t* bin_offset; // [layers * bins]
+    uint32_t* bin_items;  // record indices, grouped by bin
+    uint32_t* total_items;
+    uint32_t* err;
+    uint32_t slots, ovf_cap, items_cap;
+    int bins_x, bins_y, layers;
+};
+
+enum : uint32_t { kErrClipOverflow = 1u, kErrItemOverflow = 2u };
+
+// ------------------------------------------------------------------ vertex stages
+struct VertexIn {
+    const float4* pos;   // xyz1
+    const float2* uv;
+    const float4* nrm;
+    const float4* tan;
+    const float4* bit;
+    uint32_t nv;
+};
+struct VertexOut {       // VertexOutput of globals.wgsl:55-62, packed in four float4 streams
+    float4* clip;
+    float4* v0;          // uv.xy, tpos.xy
+    float4* v1;          // tpos.z, tlight.xyz
+    float4* v2;          // tview.xyz, wpos.x
+    float4* v3;          // wpos.yzw, 0
+};
+
+// pbr.wgsl:8-46
+__global__ __launch_bounds__(256) void k_vs_geometry(VertexIn in, VertexOut out, FrameConsts fc) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= in.nv) return;
+    float4 p = in.pos[i], n = in.nrm[i], t = in.tan[i], b = in.bit[i];
+    float2 uv = in.uv[i];
+    V3 wn = normalize3(mat3_mul(fc.normal_geom, v3(n.x, n.y, n.z)));
+    V3 wt = normalize3(mat3_mul(fc.normal_geom, v3(t.x, t.y, t.z)));
+    V3 wb = normalize3(mat3_mul(fc.normal_geom, v3(b.x, b.y, b.z)));
+    V4 wp = mat4_mul(fc.model_geom, V4{p.x, p.y, p.z, 1.0f});
+    V4 cl = mat4_mul(fc.pv, wp);
+    V3 w3 = v3(wp.x, wp.y, wp.z);
+    V3 lp = v3(fc.light_pos[0], fc.light_pos[1], fc.light_pos[2]);
+    V3 cp = v3(fc.cam_pos[0], fc.cam_pos[1], fc.cam_pos[2]);
+    out.clip[i] = make_float4(cl.x, cl.y, cl.z, cl.w);
+    out.v0[i] = make_float4(uv.x, uv.y, dot3(wt, w3), dot3(wb, w3));
+    out.v1[i] = make_float4(dot3(wn, w3), dot3(wt, lp), dot3(wb, lp), dot3(wn, lp));
+    out.v2[i] = make_float4(dot3(wt, cp), dot3(wb, cp), dot3(wn, cp), wp.x);
+    out.v3[i] = make_float4(wp.y, wp.z, wp.w, 0.0f);
+}
+
+// depth.wgsl:3-17, all six light_matrix_index values in one launch (grid.y = face)
+__global__ __launch_bounds__(256) void k_vs_shadow(const float4* pos, uint32_t nv, float4* clip, FrameConsts fc) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv) return;
+    uint32_t face = blockIdx.y;
+    float4 p = pos[i];
+    V4 wp = mat4_mul(fc.model_geom, V4{p.x, p.y, p.z, 1.0f});
+    V4 cl = mat4_mul(fc.light_m[face], wp);
+    clip[(size_t)face * nv + i] = make_float4(cl.x, cl.y, cl.z, cl.w);
+}
+
+// ------------------------------------------------------------------ triangle set-up
+__device__ inline void store_rec(Rec* dst, const Rec& r) {
+    const uint4* s = reinterpret_cast<const uint4*>(&r);
+    uint4* d = reinterpret_cast<uint4*>(dst);
+    d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3];
+}
+__device__ inline Rec load_rec(const Rec* src) {
+    Rec r;
+    const uint4* s = reinterpret_cast<const uint4*>(src);
+    uint4* d = reinterpret_cast<uint4*>(&r);
+    d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3];
+    return r;
+}
+
+template <bool SHADOW>
+__device__ __attribute__((noinline)) void emit_clipped(const V4* c, uint32_t tri, Rec* recs, uint32_t slot,
+                                                       float* betas, uint32_t* ovf_count, uint32_t slots,
+                                                       uint32_t ovf_cap, uint32_t* err, int W, int H) {
+    ClipVert poly[10];
+    for (int k = 0; k < 3; ++k) {
+        poly[k].x = c[k].x; poly[k].y = c[k].y; poly[k].z = c[k].z; poly[k].w = c[k].w;
+        poly[k].b0 = k == 0 ? 1.0f : 0.0f; poly[k].b1 = k == 1 ? 1.0f : 0.0f; poly[k].b2 = k == 2 ? 1.0f : 0.0f;
+    }
+    int n = clip_polygon(poly, 3);
+    Rec parent;
+    parent.id = kRecInvalid;
+    if (n >= 3) {
+        uint32_t nf = (uint32_t)(n - 2);
+        uint32_t base = atomicAdd(ovf_count, nf);
+        if (base + nf > ovf_cap) {
+            atomicOr(err, kErrClipOverflow);
+        } else {
+            for (uint32_t i = 0; i < nf; ++i) {
+                ClipVert cv[3] = {poly[0], poly[i + 1], poly[i + 2]};
+                Rec r;
+                float beta[9];
+                if (!setup_sub(cv, W, H, SHADOW, (tri << 3) | i, r, beta)) r.id = kRecInvalid;
+                store_rec(&recs[slots + base + i], r);
+                float* bd = betas + (size_t)(base + i) * 9;
+                for (int k = 0; k < 9; ++k) bd[k] = beta[k];
+            }
+            parent.id = kRecClippedParent;
+            parent.X0 = (int32_t)(slots + base);
+            parent.Y0 = (int32_t)nf;
+        }
+    }
+    store_rec(&recs[slot], parent);
+}
+
+template <bool SHADOW>
+__device__ inline void emit_triangle(const V4* c, uint32_t tri, Rec* recs, uint32_t slot, float* betas,
+                                     uint32_t* ovf_count, uint32_t slots, uint32_t ovf_cap, uint32_t* err,
+                                     int W, int H) {
+    int cls = classify_triangle(c);
+    if (cls == 2) {
+        emit_clipped<SHADOW>(c, tri, recs, slot, betas, ovf_count, slots, ovf_cap, err, W, H);
+        return;
+    }
+    Rec r;
+    r.id = kRecInvalid;
+    if (cls == 1) {
+        ClipVert cv[3];
+        for (int k = 0; k < 3; ++k) { cv[k].x = c[k].x; cv[k].y = c[k].y; cv[k].z = c[k].z; cv[k].w = c[k].w; cv[k].b0 = cv[k].b1 = cv[k].b2 = 0.0f; }
+        if (!setup_sub(cv, W, H, SHADOW, tri << 3, r, nullptr)) r.id = kRecInvalid;
+    }
+    store_rec(&recs[slot], r);
+}
+
+// One thread per triangle of the geometry model; grid.y = layer (cube face for shadows).
+template <bool SHADOW>
+__global__ __launch_bounds__(256) void k_setup(const float4* clip, uint32_t nv, const uint32_t* idx, uint32_t ntris,
+                                               RasterWS ws, int W, int H) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntris) return;
+    uint32_t layer = blockIdx.y;
+    const float4* cl = clip + (size_t)layer * nv;
+    V4 c[3];
+    for (int k = 0; k < 3; ++k) {
+        float4 v = cl[idx[3 * t + k]];
+        c[k] = V4{v.x, v.y, v.z, v.w};
+    }
+    Rec* recs = ws.recs + (size_t)layer * (ws.slots + ws.ovf_cap);
+    float* betas = ws.betas + (size_t)layer * ws.ovf_cap * 9;
+    emit_triangle<SHADOW>(c, t, recs, t, betas, ws.ovf_count + layer, ws.slots, ws.ovf_cap, ws.err, W, H);
+}
+
+// The two 12-triangle helper models.  mode 0: light marker (light_debug.wgsl:12-21), its
+// records continue the geometry model's slots and ids; mode 1: fog volume (fog.wgsl:14-34)
+// into its own record array.  enabled == 0 only invalidates the slots.
+__global__ void k_setup_small(const float4* pos, const uint32_t* idx, uint32_t ntris, int mode, int enabled,
+                              uint32_t slot_base, RasterWS ws, FrameConsts fc) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntris) return;
+    if (!enabled) {
+        Rec r;
+        r.id = kRecInvalid;
+        store_rec(&ws.recs[slot_base + t], r);
+        return;
+    }
+    V4 c[3];
+    for (int k = 0; k < 3; ++k) {
+        float4 p = pos[idx[3 * t + k]];
+        V4 wp;
+        if (mode == 0) wp = V4{p.x * 10.0f + fc.light_pos[0], p.y * 10.0f + fc.light_pos[1], p.z * 10.0f + fc.light_pos[2], 1.0f};
+        else wp = mat4_mul(fc.model_fog, V4{p.x, p.y, p.z, 1.0f});
+        c[k] = mat4_mul(fc.pv, wp);
+    }
+    emit_triangle<false>(c, slot_base + t, ws.recs, slot_base + t, ws.betas, ws.ovf_count, ws.slots, ws.ovf_cap,
+                         ws.err, fc.W, fc.H);
+}
+
+// ------------------------------------------------------------------ binning
+// Pass 1 (FILL = false) counts, pass 2 (FILL = true) writes record indices; both walk the
+// same bins with the same reject test, so counts and fills agree.
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_bin(RasterWS ws, int tile_rank, int tile_world) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t layer = blockIdx.y;
+    uint32_t ovf = ws.ovf_count[layer];
+    if (ovf > ws.ovf_cap) ovf = ws.ovf_cap;
+    if (i >= ws.slots + ovf) return;
+    const Rec* recs = ws.recs + (size_t)layer * (ws.slots + ws.ovf_cap);
+    Rec r = load_rec(&recs[i]);
+    if (r.id >= kRecClippedParent) return;
+    int pxmin = (int)(r.bbmin & 0xffffu), pymin = (int)(r.bbmin >> 16);
+    int pxmax = (int)(r.bbmax & 0xffffu), pymax = (int)(r.bbmax >> 16);
+    Edges e;
+    make_edges(r, e);
+    int nb = ws.bins_x * ws.bins_y;
+    for (int by = pymin / kBin; by <= pymax / kBin; ++by)
+        for (int bx = pxmin / kBin; bx <= pxmax / kBin; ++bx) {
+            int b = by * ws.bins_x + bx;
+            if (tile_world > 1 && (b % tile_world) != tile_rank) continue;
+            int x0 = imax(bx * kBin, pxmin), x1 = imin(bx * kBin + kBin - 1, pxmax);
+            int y0 = imax(by * kBin, pymin), y1 = imin(by * kBin + kBin - 1, pymax);
+            if (box_rejected(e, x0, y0, x1, y1)) continue;
+            uint32_t gb = layer * (uint32_t)nb + (uint32_t)b;
+            if (!FILL) {
+                atomicAdd(&ws.bin_count[gb], 1u);
+            } else {
+                uint32_t pos = atomicAdd(&ws.bin_cursor[gb], 1u);
+                uint32_t o = ws.bin_offset[gb] + pos;
+                if (o < ws.items_cap) ws.bin_items[o] = i;
+            }
+        }
+}
+
+// Exclusive prefix sum of the bin counts (one 1024-thread workgroup; n is a few thousand).
+__global__ __launch_bounds__(1024) void k_scan(RasterWS ws) {
+    __shared__ uint32_t part[1024];
+    uint32_t n = (uint32_t)(ws.bins_x * ws.bins_y * ws.layers);
+    uint32_t tid = threadIdx.x;
+    uint32_t chunk = (n + 1023u) / 1024u;
+    uint32_t beg = min(tid * chunk, n), end = min(beg + chunk, n);
+    uint32_t s = 0;
+    for (uint32_t k = beg; k < end; ++k) s += ws.bin_count[k];
+    part[tid] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {
+        uint32_t v = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - s;
+    for (uint32_t k = beg; k < end; ++k) {
+        ws.bin_offset[k] = run;
+        run += ws.bin_count[k];
+    }
+    if (tid == 1023u) {
+        *ws.total_items = part[1023];
+        if (part[1023] > ws.items_cap) atomicOr(ws.err, kErrItemOverflow);
+    }
+}
+
+// ------------------------------------------------------------------ rasteriser
+// One workgroup per (bin, layer).  SHADOW: depth-only, LessEqual with bias -> plain min of
+// the biased depth (pass.rs:118-126).  Otherwise depth test Less with depth write
+// (state.rs:467,482): the smallest (depth, id) key wins, ties go to the earlier draw.
+template <bool SHADOW>
+__global__ __launch_bounds__(256) void k_raster(RasterWS ws, int W, int H, uint32_t* vis, float* depth,
+                                                int tile_rank, int tile_world) {
+    __shared__ unsigned long long tile[SHADOW ? 1 : kBin * kBin];
+    __shared__ uint32_t tile32[SHADOW ? kBin * kBin : 1];
+    const int b = blockIdx.x, layer = blockIdx.y;
+    if (tile_world > 1 && (b % tile_world) != tile_rank) return;
+    const int bx = b % ws.bins_x, by = b / ws.bins_x;
+    const int ox = bx * kBin, oy = by * kBin;
+    for (int i = threadIdx.x; i < kBin * kBin; i += 256) {
+        if (SHADOW) tile32[i] = 0x3F800000u;
+        else tile[i] = 0x3F800000FFFFFFFFull;
+    }
+    __syncthreads();
+    const uint32_t gb = (uint32_t)layer * (uint32_t)(ws.bins_x * ws.bins_y) + (uint32_t)b;
+    const uint32_t n = ws.bin_count[gb], off = ws.bin_offset[gb];
+    const Rec* recs = ws.recs + (size_t)layer * (ws.slots + ws.ovf_cap);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lx = lane & 7, ly = lane >> 3;
+    for (uint32_t i = wave; i < n; i += 4) {
+        if (off + i >= ws.items_cap) break;
+        uint32_t ri = __builtin_amdgcn_readfirstlane(ws.bin_items[off + i]);
+        Rec r = load_rec(&recs[ri]);
+        Edges e;
+        make_edges(r, e);
+        int x0 = imax((int)(r.bbmin & 0xffffu), ox), x1 = imin((int)(r.bbmax & 0xffffu), ox + kBin - 1);
+        int y0 = imax((int)(r.bbmin >> 16), oy), y1 = imin((int)(r.bbmax >> 16), oy + kBin - 1);
+        for (int qy = y0 >> 3; qy <= (y1 >> 3); ++qy)
+            for (int qx = x0 >> 3; qx <= (x1 >> 3); ++qx) {
+                int bx0 = imax(qx * 8, x0), bx1 = imin(qx * 8 + 7, x1);
+                int by0 = imax(qy * 8, y0), by1 = imin(qy * 8 + 7, y1);
+                if (box_rejected(e, bx0, by0, bx1, by1)) continue;
+                int px = qx * 8 + lx, py = qy * 8 + ly;
+                if (px < x0 || px > x1 || py < y0 || py > y1) continue;
+                int64_t E[3];
+                edge_eval(e, px, py, E);
+                if (!edges_inside(e, E)) continue;
+                float z = depth_at(r, E);
+                int li = (py - oy) * kBin + (px - ox);
+                if (SHADOW) {
+                    float zb = fminf(fmaxf(z + r.iw0, 0.0f), 1.0f);
+                    atomicMin(&tile32[li], f2u(zb));
+                } else {
+                    if (z < 1.0f) atomicMin(&tile[li], ((unsigned long long)f2u(z) << 32) | (unsigned long long)r.id);
+                }
+            }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kBin * kBin; i += 256) {
+        int px = ox + (i & (kBin - 1)), py = oy + (i / kBin);
+        if (px >= W || py >= H) continue;
+        size_t o = (size_t)layer * (size_t)W * (size_t)H + (size_t)py * W + px;
+        if (SHADOW) {
+            depth[o] = u2f(tile32[i]);
+        } else {
+            unsigned long long k = tile[i];
+            vis[o] = (uint32_t)k;
+            depth[o] = u2f((uint32_t)(k >> 32));
+        }
+    }
+}
+
+// ------------------------------------------------------------------ deferred shading
+struct ShadeArgs {
+    FrameConsts fc;
+    RasterWS ws;
+    const uint32_t* vis;
+    const float* depth;
+    uint32_t* color;
+    const uint32_t* idx;
+    const uint32_t* tri_mat;
+    uint32_t ntris_geom;
+    const float4 *v0, *v1, *v2, *v3;
+    const MatDesc* mats;
+    const TexDesc* tex;
+    const uint32_t* texels;
+    const float* tables;
+    const float* shadow;
+    unsigned long long* counters;  // [0] fog fragments [1] noise evals [2] shaded fragments [3] replay pixels
+};
+
+// Interpolates the VertexOutput of one fragment and runs pbr.wgsl's fs_main on it.
+// Derivatives for the sampler's level of detail are taken per 2x2 quad on the fragment's
+// own triangle: ddx = uv(x0+1,y0) - uv(x0,y0), ddy = uv(x0,y0+1) - uv(x0,y0).
+__device__ inline V4 shade_fragment(const ShadeArgs& a, const Rec& r, const float* beta, const Edges& e,
+                                    uint32_t tri, int px, int py, const int64_t* E) {
+    uint32_t i0 = a.idx[3 * tri], i1 = a.idx[3 * tri + 1], i2 = a.idx[3 * tri + 2];
+    float4 a0 = a.v0[i0], a1 = a.v0[i1], a2 = a.v0[i2];
+    float B[3];
+    bary_at(r, beta, E, B);
+    PbrInputs in;
+    in.uv = V2{ip(B, a0.x, a1.x, a2.x), ip(B, a0.y, a1.y, a2.y)};
+    int qx = px & ~1, qy = py & ~1;
+    V2 q[3];
+    for (int k = 0; k < 3; ++k) {
+        int64_t Eq[3];
+        float Bq[3];
+        edge_eval(e, qx + (k == 1), qy + (k == 2), Eq);
+        bary_at(r, beta, Eq, Bq);
+        q[k] = V2{ip(Bq, a0.x, a1.x, a2.x), ip(Bq, a0.y, a1.y, a2.y)};
+    }
+    in.ddx = V2{q[1].x - q[0].x, q[1].y - q[0].y};
+    in.ddy = V2{q[2].x - q[0].x, q[2].y - q[0].y};
+    float4 b0 = a.v1[i0], b1 = a.v1[i1], b2 = a.v1[i2];
+    float4 c0 = a.v2[i0], c1 = a.v2[i1], c2 = a.v2[i2];
+    float4 d0 = a.v3[i0], d1 = a.v3[i1], d2 = a.v3[i2];
+    in.tpos = v3(ip(B, a0.z, a1.z, a2.z), ip(B, a0.w, a1.w, a2.w), ip(B, b0.x, b1.x, b2.x));
+    in.tlight = v3(ip(B, b0.y, b1.y, b2.y), ip(B, b0.z, b1.z, b2.z), ip(B, b0.w, b1.w, b2.w));
+    in.tview = v3(ip(B, c0.x, c1.x, c2.x), ip(B, c0.y, c1.y, c2.y), ip(B, c0.z, c1.z, c2.z));
+    in.wpos = V4{ip(B, c0.w, c1.w, c2.w), ip(B, d0.x, d1.x, d2.x), ip(B, d0.y, d1.y, d2.y), ip(B, d0.z, d1.z, d2.z)};
+    ShadowMap sm{a.shadow, a.fc.S};
+    ColorTables ct{a.tables};
+    return fs_pbr(a.fc, sm, a.texels, a.tex, a.mats[a.tri_mat[tri]], ct, in);
+}
+
+// Resolves (triangle id, fan index) to its record and clip weights.
+__device__ inline Rec fetch_rec(const RasterWS& ws, uint32_t id, const float*& beta) {
+    Rec r = load_rec(&ws.recs[id >> 3]);
+    beta = nullptr;
+    if (r.id == kRecClippedParent) {
+        uint32_t ri = (uint32_t)r.X0 + (id & 7u);
+        beta = ws.betas + (size_t)(ri - ws.slots) * 9;
+        r = load_rec(&ws.recs[ri]);
+    }
+    return r;
+}
+
+// Ordered blending for a pixel whose front-most fragment is not opaque: replays, in draw
+// order, every fragment that passed the depth test when it was drawn (geometry pass blends
+// SrcAlpha/OneMinusSrcAlpha with depth writes on, state.rs:465-467; the light marker is
+// drawn after it with REPLACE, state.rs:480-482).
+__device__ __attribute__((noinline)) uint32_t replay_pixel(const ShadeArgs& a, int px, int py) {
+    const RasterWS& ws = a.ws;
+    ColorTables ct{a.tables};
+    int b = (py / kBin) * ws.bins_x + (px / kBin);
+    uint32_t n = ws.bin_count[b], off = ws.bin_offset[b];
+    uint32_t col = 0xFF000000u;
+    float d = 1.0f;
+    long long last = -1;
+    for (;;) {
+        uint32_t best = 0xFFFFFFFFu, best_ri = 0;
+        float best_z = 0.0f;
+        for (uint32_t i = 0; i < n; ++i) {
+            uint32_t ri = ws.bin_items[off + i];
+            const Rec* rp = &ws.recs[ri];
+            uint32_t id = rp->id;
+            if ((long long)id <= last || id >= best) continue;
+            uint32_t bbmin = rp->bbmin, bbmax = rp->bbmax;
+            if (px < (int)(bbmin & 0xffffu) || px > (int)(bbmax & 0xffffu) || py < (int)(bbmin >> 16) || py > (int)(bbmax >> 16)) continue;
+            Rec r = load_rec(rp);
+            Edges e;
+            make_edges(r, e);
+            int64_t E[3];
+            edge_eval(e, px, py, E);
+            if (!edges_inside(e, E)) continue;
+            float z = depth_at(r, E);
+            if (!(z < d)) continue;
+            best = id; best_ri = ri; best_z = z;
+        }
+        if (best == 0xFFFFFFFFu) break;
+        uint32_t tri = best >> 3;
+        if (tri >= a.ntris_geom) {
+            col = blend_pack(ct, col, V4{a.fc.light_color[0], a.fc.light_color[1], a.fc.light_color[2], 1.0f}, false);
+        } else {
+            Rec r = load_rec(&ws.recs[best_ri]);
+            const float* beta = best_ri >= ws.slots ? ws.betas + (size_t)(best_ri - ws.slots) * 9 : nullptr;
+            Edges e;
+            make_edges(r, e);
+            int64_t E[3];
+            edge_eval(e, px, py, E);
+            V4 src = shade_fragment(a, r, beta, e, tri, px, py, E);
+            col = blend_pack(ct, col, src, true);
+        }
+        d = best_z;
+        last = (long long)best;
+    }
+    return col;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
+    // 16x16 pixels per workgroup, each wavefront an 8x8 block
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int py = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    if (px >= a.fc.W || py >= a.fc.H) return;
+    if (a.fc.tile_world > 1) {
+        int b = (py / kBin) * a.ws.bins_x + (px / kBin);
+        if ((b % a.fc.tile_world) != a.fc.tile_rank) return;
+    }
+    const size_t pi = (size_t)py * a.fc.W + px;
+    const uint32_t id = a.vis[pi];
+    ColorTables ct{a.tables};
+    if (id == kVisNone) { a.color[pi] = 0xFF000000u; return; }  // clear colour (0,0,0,1), state.rs:696-701
+    const uint32_t tri = id >> 3;
+    if (tri >= a.ntris_geom) {  // light marker, light_debug.wgsl:23-26
+        a.color[pi] = blend_pack(ct, 0u, V4{a.fc.light_color[0], a.fc.light_color[1], a.fc.light_color[2], 1.0f}, false);
+        return;
+    }
+    const float* beta;
+    Rec r = fetch_rec(a.ws, id, beta);
+    Edges e;
+    make_edges(r, e);
+    int64_t E[3];
+    edge_eval(e, px, py, E);
+    V4 src = shade_fragment(a, r, beta, e, tri, px, py, E);
+    if (COUNT) atomicAdd(&a.counters[2], 1ull);
+    uint32_t col;
+    if (src.w == 1.0f) {
+        col = blend_pack(ct, 0u, src, false);  // alpha 1 replaces whatever was blended before
+    } else {
+        if (COUNT) atomicAdd(&a.counters[3], 1ull);
+        col = replay_pixel(a, px, py);
+    }
+    a.color[pi] = col;
+}
+
+// ------------------------------------------------------------------ fog
+struct FogArgs {
+    FrameConsts fc;
+    RasterWS ws;          // fog volume records (no bins)
+    const float4* pos;    // fog model positions
+    const uint32_t* idx;
+    uint32_t ntris;
+    const float* depth;   // geometry depth: depth test (Less, no write) and fog.wgsl:131
+    uint32_t* color;
+    const float* shadow;
+    const float* tables;
+    unsigned long long* counters;
+};
+
+// Fog pass, state.rs:763-804: every front-facing fog-volume fragment that passes the depth
+// test runs fog.wgsl's fs_main and is blended over the colour target, in draw order.
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_fog(FogArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int py = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    if (px >= a.fc.W || py >= a.fc.H) return;
+    if (a.fc.tile_world > 1) {
+        int b = (py / kBin) * ((a.fc.W + kBin - 1) / kBin) + (px / kBin);
+        if ((b % a.fc.tile_world) != a.fc.tile_rank) return;
+    }
+    const size_t pi = (size_t)py * a.fc.W + px;
+    const float zbuf = a.depth[pi];
+    ColorTables ct{a.tables};
+    ShadowMap sm{a.shadow, a.fc.S};
+    uint32_t col = a.color[pi];
+    bool touched = false;
+    for (uint32_t t = 0; t < a.ntris; ++t) {
+        Rec slot = load_rec(&a.ws.recs[t]);
+        if (slot.id == kRecInvalid) continue;
+        uint32_t first = t, count = 1;
+        if (slot.id == kRecClippedParent) { first = (uint32_t)slot.X0; count = (uint32_t)slot.Y0; }
+        for (uint32_t s = 0; s < count; ++s) {
+            uint32_t ri = first + s;
+            Rec r = (slot.id == kRecClippedParent) ? load_rec(&a.ws.recs[ri]) : slot;
+            if (r.id >= kRecClippedParent) continue;
+            if (px < (int)(r.bbmin & 0xffffu) || px > (int)(r.bbmax & 0xffffu) || py < (int)(r.bbmin >> 16) || py > (int)(r.bbmax >> 16)) continue;
+            Edges e;
+            make_edges(r, e);
+            int64_t E[3];
+            edge_eval(e, px, py, E);
+            if (!edges_inside(e, E)) continue;
+            float z = depth_at(r, E);
+            if (!(z < zbuf)) continue;
+            const float* beta = ri >= a.ws.slots ? a.ws.betas + (size_t)(ri - a.ws.slots) * 9 : nullptr;
+            float B[3];
+            bary_at(r, beta, E, B);
+            V4 w[3];
+            for (int k = 0; k < 3; ++k) {
+                float4 p = a.pos[a.idx[3 * t + k]];
+                w[k] = mat4_mul(a.fc.model_fog, V4{p.x, p.y, p.z, 1.0f});
+            }
+            V3 origin = v3(ip(B, w[0].x, w[1].x, w[2].x), ip(B, w[0].y, w[1].y, w[2].y), ip(B, w[0].z, w[1].z, w[2].z));
+            uint32_t evals = 0;
+            V4 src = fs_fog(a.fc, sm, a.depth, origin, z, px, py, evals);
+            if (COUNT) {
+                atomicAdd(&a.counters[0], 1ull);
+                atomicAdd(&a.counters[1], (unsigned long long)evals);
+            }
+            col = blend_pack(ct, col, src, true);
+            touched = true;
+        }
+    }
+    if (touched) a.color[pi] = col;
+}
+
+// ------------------------------------------------------------------ bin pack / scatter
+// Moves whole 64x64 colour bins between the frame and a packed [bin][64][64] buffer, for
+// gathering a frame whose bins were rendered on different devices.
+__global__ __launch_bounds__(256) void k_pack_bins(const uint32_t* color, uint32_t* packed, int W, int H, int bins_x,
+                                                   int nbins, int rank, int world, int to_packed) {
+    int j = blockIdx.x;                 // j-th bin owned by `rank`
+    int b = rank + j * world;
+    if (b >= nbins) return;
+    int ox = (b % bins_x) * kBin, oy = (b / bins_x) * kBin;
+    for (int i = threadIdx.x; i < kBin * kBin; i += 256) {
+        int px = ox + (i & (kBin - 1)), py = oy + i / kBin;
+        size_t po = (size_t)j * kBin * kBin + i;
+        bool in = px < W && py < H;
+        if (to_packed) packed[po] = in ? color[(size_t)py * W + px] : 0u;
+        else if (in) const_cast<uint32_t*>(color)[(size_t)py * W + px] = packed[po];
+    }
+}
+
+__global__ void k_fill_f32(float* p, size_t n, float v) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+}  // namespace wr
