@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""Benchmark of the render hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one full frame of BASELINE.json configs[2]: the Sponza-class scene at 1920x1080
+with the six shadow passes, PBS shading with PCF, the light marker and the fog pass, every
+stage recomputed each frame as State::render does (state.rs:630-809).  With N > 1 (launched
+by torch.distributed.run, one rank per GPU) every rank renders its own frames: frames shard
+across GPUs with no data-path collective ("scaling": "weak"); `value` is frames of all
+ranks divided by the slowest rank's time.
+
+Other workloads (not the default line): --workload posebatch renders the 512-pose
+flythrough split contiguously over the ranks (wr_render_batch), --workload tiles4k renders
+3840x2160 with screen bins interleaved over the ranks and gathers them on rank 0 through
+torch.distributed (RCCL all_gather).
+
+res/models/Sponza.glb is not part of the reference checkout, so the scene is the procedural
+stand-in of wgpu_renderer_amd.scene (about 262k triangles, 25 materials, 1024^2 textures)
+unless --sponza PATH names a real file.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+# Algorithmic f32 operations of one executed fog_noise evaluation inside ray_march
+# (fog.wgsl:64-85 + 48-62, noise.wgsl): 2 fbm x 8 octaves x (8 hashes of 29-32 ops incl. a
+# 19-op software sine, smoothstep, 7 mixes) + the march bookkeeping; a fused multiply-add
+# counts as 2.  Derivation in DESIGN.md, "fog kernel".
+FLOP_PER_FOG_NOISE_EVAL = 5198
+PEAK_FP32_TFLOPS = 157.3   # MI355X f32 vector peak = dense f32 matrix peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def build_scene(args):
+    import wgpu_renderer_amd  # noqa: F401
+    from wgpu_renderer_amd import abi, scene
+
+    if args.sponza and os.path.exists(args.sponza):
+        from wgpu_renderer_amd import gltf_loader
+        model, textures = gltf_loader.load_glb(args.sponza)
+        cube = scene.cube_model()
+        sc = scene.Scene(textures, model, cube, scene.cube_model(),
+                         abi.instance_raw(scene.REFERENCE_GEOMETRY_INSTANCE["position"]),
+                         abi.instance_raw(scene.REFERENCE_FOG_INSTANCE["position"], (1, 0, 0, 0), scene.REFERENCE_FOG_INSTANCE["scale"]))
+        return sc, os.path.basename(args.sponza)
+    return scene.sponza_standin(detail=args.detail, tex_size=args.tex_size), "procedural Sponza stand-in (seed 0x5EED)"
+
+
+def algorithmic_bytes(sc, W, H, S, covered, fog_frags):
+    """Compulsory HBM traffic of one frame: shadow 6x(V*12 + I*4) read + 6*S^2*4 written;
+    raster V*12 + I*4 read + W*H*8 written; shade covered*(8 + 3*56 + 3*4 + 16*4) + W*H*4
+    written; fog fragments*(4 + 4 + 4 + 64)."""
+    V = sc.geometry.vertex_count
+    I = sc.geometry.triangle_count * 3
+    shadow = 6 * (V * 12 + I * 4) + 6 * S * S * 4
+    raster = V * 12 + I * 4 + W * H * 8
+    shade = covered * (8 + 3 * 56 + 3 * 4 + 16 * 4) + W * H * 4
+    fog = fog_frags * (4 + 4 + 4 + 64)
+    return shadow + raster + shade + fog
+
+
+def cpu_baseline(sc, cam, light, glob, passes, W, H, S, threads):
+    """Times the CPU restatement (oracle/) on one full frame of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import Oracle
+
+    o = Oracle(W, H, S)
+    o.upload_scene(sc)
+    t0 = time.perf_counter()
+    o.render_frame(cam, light, glob, passes, threads=threads)
+    dt = time.perf_counter() - t0
+    cnt = o.counters()
+    o.close()
+    return dt, cnt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=["frame", "posebatch", "tiles4k"], default="frame")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--shadow-size", type=int, default=2048)
+    ap.add_argument("--detail", type=float, default=1.0)
+    ap.add_argument("--tex-size", type=int, default=1024)
+    ap.add_argument("--time", type=float, default=2.0, help="animation time t (state.rs:609-617)")
+    ap.add_argument("--sponza", type=str, default=os.environ.get("WR_SPONZA_GLB", ""))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--poses", type=int, default=512)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+
+    import wgpu_renderer_amd  # noqa: F401
+    from wgpu_renderer_amd import abi, scene
+
+    sc, scene_name = build_scene(args)
+    W, H, S = args.width, args.height, args.shadow_size
+    if args.workload == "tiles4k":
+        W, H = 3840, 2160
+    passes = abi.PASS_ALL
+    light = abi.light_at_time(args.time)
+    glob = abi.global_uniforms(args.time, 1)
+    rc = scene.REFERENCE_CAMERA
+    cam = abi.camera_uniform(rc["position"], rc["pitch"], rc["yaw"], rc["fovy"], W, H)
+
+    tile_world = world if args.workload == "tiles4k" else 1
+    r = abi.Renderer(W, H, S, device=local_rank, tile_rank=rank if tile_world > 1 else 0, tile_world=tile_world)
+    r.upload_scene(sc)
+
+    def barrier():
+        torch.cuda.synchronize()
+        r.sync()
+        if world > 1:
+            dist.barrier()
+
+    gather_buf = packed = None
+    if args.workload == "tiles4k" and world > 1:
+        nb = ((W + 63) // 64) * ((H + 63) // 64)
+        per = (nb + world - 1) // world
+        packed = torch.zeros(per * 64 * 64, dtype=torch.int32, device="cuda")
+        gather_buf = torch.zeros(world * per * 64 * 64, dtype=torch.int32, device="cuda")
+
+    poses = None
+    if args.workload == "posebatch":
+        per_rank = args.poses // world
+        mine = range(rank * per_rank, (rank + 1) * per_rank)
+
+        def pose_camera(k):
+            pos, pitch, yaw = scene.flythrough_pose(k, args.poses)
+            return abi.camera_uniform(pos, pitch, yaw, rc["fovy"], W, H)
+
+        poses = [pose_camera(k) for k in mine]
+
+    def step(i):
+        if args.workload == "posebatch":
+            r.render_frame(poses[i % len(poses)], light, glob, passes)
+        else:
+            r.render_frame(cam, light, glob, passes)
+            if gather_buf is not None:
+                r.sync()
+                r.pack_owned_bins(packed.data_ptr())
+                r.sync()
+                dist.all_gather_into_tensor(gather_buf, packed)
+
+    # one counted frame (outside the timed region) for the algorithmic work of this frame
+    r.set_counting(True)
+    step(0)
+    st = r.stats()
+    fog_frags, noise_evals, shaded = int(st.fog_fragments), int(st.fog_noise_evals), int(st.shaded_fragments)
+    r.set_counting(False)
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    r.set_profiling(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    r.sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    st = r.stats()
+    r.set_profiling(False)
+
+    frames_per_step = 1 if args.workload != "tiles4k" else 1.0 / world  # tiles: all ranks share one frame
+    total_frames = args.steps * world * frames_per_step
+    fps = total_frames / dt
+
+    out = None
+    if rank == 0:
+        fog_s = st.ms_fog * 1e-3
+        fog_flops = FLOP_PER_FOG_NOISE_EVAL * noise_evals
+        frame_bytes = algorithmic_bytes(sc, W, H, S, shaded, fog_frags)
+        roofline = {
+            "kernel": "k_fog (fog.wgsl fragment stage: ray march through 8-octave value noise)",
+            "bound": "valu",
+            "achieved": (fog_flops / fog_s) / 1e12 if fog_s > 0 else None,
+            "peak": PEAK_FP32_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": ((fog_flops / fog_s) / 1e12) / PEAK_FP32_TFLOPS if fog_s > 0 else None,
+            "traffic": None,
+            "launch_ms": st.ms_fog,
+            "launches_averaged": int(st.profiled_frames),
+            "flop_per_launch": fog_flops,
+        }
+        stage_ms = {"shadow": st.ms_shadow, "geometry": st.ms_geometry, "shade": st.ms_shade, "fog": st.ms_fog}
+        hbm = {
+            "algorithmic_bytes_per_frame": frame_bytes,
+            "achieved_GBps": frame_bytes * fps / world / 1e9,
+            "peak_GBps": PEAK_HBM_GBS,
+            "frac": frame_bytes * fps / world / 1e9 / PEAK_HBM_GBS,
+        }
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(args.cpu_threads, os.cpu_count() or 1)
+            cdt, ccnt = cpu_baseline(sc, cam, light, glob, passes, W, H, S, threads)
+            cpu = {
+                "value": 1.0 / cdt, "unit": "frames/s", "cores": threads, "kind": "port",
+                "sample": f"1 full frame of the same workload ({W}x{H}, shadows+fog) on the CPU restatement in oracle/ "
+                          f"(reference wgpu-on-lavapipe path not buildable offline); {cdt:.2f} s",
+                "fog_noise_evals": int(ccnt["fog_noise_evals"]),
+            }
+        out = {
+            "metric": "frames/sec Sponza 1080p shadows+fog" if args.workload == "frame" else f"frames/sec {args.workload}",
+            "value": fps,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak" if args.workload != "tiles4k" else "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": {"frame": f"configs[2]: Sponza-class scene {W}x{H}, shadow map 6x{S}^2 + PCF, PBS, light marker, fog; "
+                                      "reference default camera (-500,150,0) yaw 0, t=2.0; every pass recomputed each frame",
+                             "posebatch": f"configs[4]: {args.poses}-pose flythrough at {W}x{H}, shadows+fog, poses split contiguously over ranks",
+                             "tiles4k": "configs[3]: 3840x2160 shadows+fog, 64x64 bins interleaved over ranks, RCCL all_gather of colour bins"}[args.workload],
+                "scene": scene_name,
+                "triangles": sc.geometry.triangle_count,
+                "vertices": sc.geometry.vertex_count,
+                "materials": len(sc.geometry.materials),
+                "texture_size": args.tex_size if "stand-in" in scene_name else None,
+                "parallelism": f"frame-parallel x{world}" if args.workload != "tiles4k" else f"screen-bin sharded x{world}",
+            },
+            "stage_ms": stage_ms,
+            "fog_fragments": fog_frags,
+            "fog_noise_evals": noise_evals,
+            "shaded_fragments": shaded,
+            "roofline": roofline,
+            "roofline_hbm_frame": hbm,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

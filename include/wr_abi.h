@@ -123,9 +123,9 @@ typedef struct WrConfig {
 
 typedef struct WrContext WrContext;
 
-/* Per-frame counters and per-stage device times of the last wr_render_frame call, read
- * after wr_sync.  Times are HIP-event milliseconds on the context's stream and are only
- * recorded while wr_set_profiling(ctx, 1) is in effect.  No counterpart in the reference
+/* Per-stage device times and per-frame counters.  Times are HIP-event milliseconds on the
+ * context's stream, averaged over the (at most 128 most recent) frames rendered since
+ * wr_set_profiling(ctx, 1); counters are those of the last frame.  No counterpart in the reference
  * (timestamp_writes: None on every pass, state.rs:660,713,749,788). */
 typedef struct WrFrameStats {
     float ms_shadow;   /* shadow vertex + setup + binning + raster, six faces */
@@ -133,6 +133,7 @@ typedef struct WrFrameStats {
     float ms_shade;    /* deferred PBS shading incl. PCF and ordered blending */
     float ms_fog;      /* fog volume raster + march */
     float ms_total;
+    uint32_t profiled_frames;    /* frames the averages above cover */
     uint32_t geometry_bin_items; /* (triangle, 64x64 bin) pairs the geometry rasteriser processed */
     uint32_t shadow_bin_items;   /* same for the six shadow faces together */
     uint64_t fog_fragments;      /* fog fragments that passed the depth test (counting mode only) */

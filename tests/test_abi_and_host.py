@@ -1,0 +1,191 @@
+"""CPU-only checks of the boundary: the library loads, exports every symbol include/wr_abi.h
+declares, struct layouts match the reference's #[repr(C)] structs, and the host scene math
+(camera.rs / light.rs / instance.rs mirrors) agrees with closed-form values."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import wgpu_renderer_amd  # noqa: F401
+from wgpu_renderer_amd import abi, scene
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "wr_abi.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(wr_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    lib = abi.load_library()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in wr_abi.h but not exported"
+    assert declared == set(abi.SYMBOLS), declared ^ set(abi.SYMBOLS)
+
+
+def test_struct_layouts_match_reference():
+    # model.rs:14-22, instance.rs:9-14, camera.rs:104-112, light.rs:11-18, state.rs:21-28
+    assert abi.VERTEX_FLOATS * 4 == 56
+    assert C.sizeof(abi.InstanceRaw) == 100
+    assert C.sizeof(abi.CameraUniform) == 224
+    assert C.sizeof(abi.LightUniform) == 416
+    assert abi.LightUniform.color.offset == 16 and abi.LightUniform.matrices.offset == 32
+    assert C.sizeof(abi.GlobalUniforms) == 16
+    assert abi.CameraUniform.position.offset == 192 and abi.CameraUniform.planes.offset == 208
+
+
+def test_create_without_device_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present")
+    with pytest.raises(abi.WrError):
+        abi.Renderer(64, 64, 64)
+
+
+def _m(a):
+    return np.array(a, dtype=np.float64).reshape(4, 4).T  # column-major -> math layout
+
+
+def test_camera_uniform_matches_closed_form():
+    w, h = 1920, 1080
+    cu = abi.camera_uniform((-500.0, 150.0, 0.0), 0.0, 0.0, 55.0, w, h)
+    view, proj = _m(cu.view), _m(cu.proj)
+    # yaw 0, pitch 0: forward +x, right +z, up +y (camera.rs:61-76)
+    p = view @ np.array([-500.0 + 10.0, 150.0, 0.0, 1.0])
+    assert np.allclose(p[:3], [0, 0, -10], atol=1e-4)  # 10 units ahead = -z in view space
+    f = 1.0 / np.tan(np.radians(55.0) / 2)
+    assert np.isclose(proj[0, 0], f / (w / h), rtol=1e-6) and np.isclose(proj[1, 1], f, rtol=1e-6)
+    n, fa = 1.0, 3000.0
+    assert np.isclose(proj[2, 2], (fa + n) / (n - fa), rtol=1e-6)
+    assert np.isclose(proj[2, 3], 2 * fa * n / (n - fa), rtol=1e-6)
+    assert proj[3, 2] == -1.0
+    assert list(cu.planes) == [1.0, 3000.0, float(w), float(h)]
+    assert list(cu.position) == [-500.0, 150.0, 0.0, 1.0]
+    inv = _m(cu.inv_view_proj)
+    ref = np.linalg.inv(proj @ view)
+    assert np.allclose(inv, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+
+
+def test_camera_pitch_yaw_vectors():
+    cu = abi.camera_uniform((0.0, 0.0, 0.0), 30.0, 90.0, 55.0, 100, 100)
+    view = _m(cu.view)
+    fwd = np.array([np.cos(np.radians(30)) * np.cos(np.radians(90)), np.sin(np.radians(30)), np.cos(np.radians(30)) * np.sin(np.radians(90))])
+    assert np.allclose(view[:3, :3] @ fwd, [0, 0, -1], atol=1e-6)
+
+
+def test_light_matrices_and_animation():
+    lu = abi.light_at_time(2.0)
+    # state.rs:610-617
+    assert np.isclose(lu.position[0], np.sin(1.0) * 500, rtol=1e-6)
+    assert np.isclose(lu.position[1], 250 + np.sin(0.6) * 200, rtol=1e-6)
+    assert np.isclose(lu.position[2], np.sin(1.6) * 100, rtol=1e-6)
+    assert np.isclose(lu.color[0], abs(np.sin(2.0)), rtol=1e-6) and lu.color[3] == 250000.0
+    pos = np.array(list(lu.position), dtype=np.float64)
+    dirs = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]  # light.rs:35-40
+    for i, d in enumerate(dirs):
+        m = _m(lu.matrices[i])
+        q = m @ np.append(pos + 100.0 * np.array(d), 1.0)
+        ndc = q[:3] / q[3]
+        assert abs(ndc[0]) < 1e-4 and abs(ndc[1]) < 1e-4 and q[3] > 0  # looks down its axis
+        # 90 degree frustum: a point at 45 degrees lands on the clip edge
+        up = {0: (0, 1, 0), 1: (0, 1, 0), 2: (1, 0, 0), 3: (-1, 0, 0), 4: (0, 1, 0), 5: (0, 1, 0)}[i]
+        q = m @ np.append(pos + 100.0 * np.array(d) + 100.0 * np.array(up), 1.0)
+        assert np.isclose(q[1] / q[3], 1.0, atol=1e-4)
+    # t = 0 gives a black light (|sin 0| = 0)
+    z = abi.light_at_time(0.0)
+    assert list(z.color)[:3] == [0.0, 0.0, 0.0]
+
+
+def test_instance_to_raw_is_T_S_R():
+    ir = abi.instance_raw((0.0, 30.0, 0.0), (1, 0, 0, 0), (1360.0, 30.0, 600.0))  # state.rs:421-425
+    m = _m(ir.model)
+    assert np.allclose(m, [[1360, 0, 0, 0], [0, 30, 0, 30], [0, 0, 600, 0], [0, 0, 0, 1]])
+    assert np.allclose(np.array(ir.normal).reshape(3, 3), np.eye(3))
+    c, s = np.cos(np.pi / 8), np.sin(np.pi / 8)  # 45 degrees about y
+    ir = abi.instance_raw((1.0, 2.0, 3.0), (c, 0.0, s, 0.0), (2.0, 3.0, 4.0))
+    R = np.array(ir.normal, dtype=np.float64).reshape(3, 3).T
+    assert np.allclose(R @ [1, 0, 0], [np.cos(np.pi / 4), 0, -np.sin(np.pi / 4)], atol=1e-6)
+    m = _m(ir.model)
+    assert np.allclose(m[:3, :3], np.diag([2, 3, 4]) @ R, atol=1e-6) and np.allclose(m[:3, 3], [1, 2, 3])
+
+
+def test_camera_fly_update_matches_reference_rules():
+    lib = abi.load_library()
+    pose = (C.c_float * 5)(0.0, 0.0, 0.0, 80.0, 350.0)
+    inp = (C.c_float * 5)(300.0, -600.0, 1.0, 0.0, 0.0)
+    lib.wr_camera_fly_update(pose, inp, 400.0, 2.0, 0.5)
+    assert pose[3] == 89.0                      # pitch clamp, camera.rs:80-84
+    assert np.isclose(pose[4], (350.0 + 300 * 2 * 0.022) % 360.0, atol=1e-4)  # yaw wrap, camera.rs:85-89
+    assert np.isclose(np.linalg.norm([pose[0], pose[1], pose[2]]), 200.0, rtol=1e-5)  # speed*dt
+
+
+def test_cube_asset_matches_reference_glb():
+    ref = "/root/reference/res/models/Cube.glb"
+    if not os.path.exists(ref):
+        pytest.skip("reference checkout not present")
+    from wgpu_renderer_amd import gltf_loader
+    model, textures = gltf_loader.load_glb(ref)
+    cube = scene.cube_model().meshes[0]
+    assert np.array_equal(model.meshes[0].vertices, cube.vertices)
+    assert np.array_equal(model.meshes[0].indices, cube.indices)
+    v = cube.vertices
+    assert v.shape == (36, 14) and np.abs(v[:, 0:3]).max() <= 1.000002
+    # bitangent = normal x tangent (mesh.rs:61-64)
+    assert np.allclose(v[:, 11:14], np.cross(v[:, 5:8], v[:, 8:11]))
+    mat = model.materials[0]
+    assert textures[mat.base][1] is True and textures[mat.normal][1] is False
+    assert textures[mat.normal][0] is textures[mat.base][0]  # missing normal map -> image 0 (resources.rs:74)
+    assert np.unique(textures[mat.mr][0].reshape(-1, 4), axis=0).tolist() == [[0, 20, 0, 255]]
+
+
+def test_gltf_loader_without_tangents_gives_nan(tmp_path):
+    # mesh.rs:67-69,151-155: calc_tangents runs on an empty index list and divides by zero
+    import json
+    import struct
+    from wgpu_renderer_amd import gltf_loader
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    nrm = np.array([[0, 0, 1]] * 3, np.float32)
+    uv = np.array([[0, 0], [1, 0], [0, 1]], np.float32)
+    idx = np.array([0, 1, 2], np.uint16)
+    blobs = [pos.tobytes(), nrm.tobytes(), uv.tobytes(), idx.tobytes() + b"\0\0"]
+    views, off = [], 0
+    for b in blobs:
+        views.append({"buffer": 0, "byteOffset": off, "byteLength": len(b)})
+        off += len(b)
+    js = {
+        "asset": {"version": "2.0"}, "buffers": [{"byteLength": off}], "bufferViews": views,
+        "accessors": [
+            {"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"},
+            {"bufferView": 1, "componentType": 5126, "count": 3, "type": "VEC3"},
+            {"bufferView": 2, "componentType": 5126, "count": 3, "type": "VEC2"},
+            {"bufferView": 3, "componentType": 5123, "count": 3, "type": "SCALAR"}],
+        "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "NORMAL": 1, "TEXCOORD_0": 2}, "indices": 3}]}],
+    }
+    jb = json.dumps(js).encode()
+    jb += b" " * (-len(jb) % 4)
+    bb = b"".join(blobs)
+    glb = struct.pack("<4sII", b"glTF", 2, 12 + 8 + len(jb) + 8 + len(bb)) + struct.pack("<I4s", len(jb), b"JSON") + jb + struct.pack("<I4s", len(bb), b"BIN\0") + bb
+    p = tmp_path / "t.glb"
+    p.write_bytes(glb)
+    model, textures = gltf_loader.load_glb(str(p))
+    v = model.meshes[0].vertices
+    assert np.isnan(v[:, 8:14]).all() and model.meshes[0].material == 0
+    assert model.meshes[0].indices.dtype == np.uint32 and model.meshes[0].indices.tolist() == [0, 1, 2]
+
+
+def test_standin_scene_is_deterministic_and_sized():
+    a = scene.sponza_standin(detail=0.1, tex_size=16)
+    b = scene.sponza_standin(detail=0.1, tex_size=16)
+    assert a.geometry.triangle_count == b.geometry.triangle_count > 1000
+    for ma, mb in zip(a.geometry.meshes, b.geometry.meshes):
+        assert np.array_equal(ma.vertices, mb.vertices) and np.array_equal(ma.indices, mb.indices)
+    for (ta, sa), (tb, sb) in zip(a.textures, b.textures):
+        assert sa == sb and np.array_equal(ta, tb)
+    assert len(a.geometry.materials) == 25 and len(a.textures) == 75
+    # some materials carry alpha < 1 texels (ordered-blend path), tangent frames are orthonormal
+    assert any((t[..., 3] < 255).any() for t, s in a.textures if s)
+    v = a.geometry.meshes[2].vertices
+    assert np.allclose(np.linalg.norm(v[:, 5:8], axis=1), 1, atol=1e-4)
+    assert np.allclose(np.sum(v[:, 5:8] * v[:, 8:11], axis=1), 0, atol=1e-4)

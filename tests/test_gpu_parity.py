@@ -1,0 +1,356 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the
+same inputs.
+
+Bar (BASELINE.json north_star): triangle-id coverage equal on >= 99.9 % of pixels with
+differences only on edges, colour PSNR >= 45 dB and max abs error <= 2/255 on non-edge
+pixels.  Because both sides follow one arithmetic contract the tests first assert the
+stronger property that holds today -- visibility, depth and shadow maps bit-identical --
+and then the tolerance on colour.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import wgpu_renderer_amd  # noqa: F401
+from wgpu_renderer_amd import abi, scene
+from golden_inputs import GOLDEN, cube_config1, standin_small
+from oracle_lib import Oracle
+from parity import compare
+
+pytestmark = pytest.mark.gpu
+
+PSNR_MIN = 45.0      # dB, north_star
+MAX_ERR_NON_EDGE = 2  # /255, north_star
+ID_MATCH_MIN = 0.999
+
+
+def render_gpu(sc, cam, light, glob, passes, w, h, s, counting=False, **kw):
+    r = abi.Renderer(w, h, s, **kw)
+    r.upload_scene(sc)
+    r.set_counting(counting)
+    r.render_frame(cam, light, glob, passes)
+    r.sync()
+    out = dict(color=r.read_color(), depth=r.read_depth(), vis=r.read_visibility())
+    if passes & abi.PASS_SHADOWS:
+        out["shadow"] = r.read_shadow_map()
+    if counting:
+        st = r.stats()
+        out["counters"] = dict(fog_fragments=int(st.fog_fragments), fog_noise_evals=int(st.fog_noise_evals))
+    r.close()
+    return out
+
+
+def render_oracle(sc, cam, light, glob, passes, w, h, s, threads=16):
+    o = Oracle(w, h, s)
+    o.upload_scene(sc)
+    o.render_frame(cam, light, glob, passes, threads=threads)
+    out = dict(color=o.read_color(), depth=o.read_depth(), vis=o.read_visibility(), counters=o.counters())
+    if passes & abi.PASS_SHADOWS:
+        out["shadow"] = o.read_shadow_map()
+    o.close()
+    return out
+
+
+def assert_parity(g, o, exact=True):
+    m = compare(o["vis"], g["vis"], o["color"], g["color"])
+    assert m["id_match"] >= ID_MATCH_MIN and m["id_mismatch_off_edge"] == 0, m
+    assert m["psnr"] >= PSNR_MIN and m["max_err_non_edge"] <= MAX_ERR_NON_EDGE, m
+    if exact:
+        assert np.array_equal(g["vis"], o["vis"]), m
+        assert np.array_equal(g["depth"], o["depth"])
+        if "shadow" in g:
+            assert np.array_equal(g["shadow"], o["shadow"])
+    return m
+
+
+def default_inputs(w, h, t=2.0, use_shadows=1, pose=None):
+    rc = scene.REFERENCE_CAMERA
+    pos, pitch, yaw = pose if pose else (rc["position"], rc["pitch"], rc["yaw"])
+    return abi.camera_uniform(pos, pitch, yaw, rc["fovy"], w, h), abi.light_at_time(t), abi.global_uniforms(t, use_shadows)
+
+
+def test_all_passes_small_scene(small_scene):
+    w, h, s = 480, 270, 512
+    cam, light, glob = default_inputs(w, h)
+    g = render_gpu(small_scene, cam, light, glob, abi.PASS_ALL, w, h, s, counting=True)
+    o = render_oracle(small_scene, cam, light, glob, abi.PASS_ALL, w, h, s)
+    assert_parity(g, o)
+    # executed march steps are integer work: must agree exactly
+    assert g["counters"]["fog_fragments"] == o["counters"]["fog_fragments"] > 0
+    assert g["counters"]["fog_noise_evals"] == o["counters"]["fog_noise_evals"] > 0
+    assert o["counters"]["blended_lt1"] > 0  # the ordered-blend path was exercised
+
+
+def test_pbs_only_small_scene(small_scene):
+    # BASELINE configs[1] shape: no shadow passes, use_shadowmaps = 0, no fog (the wasm32 build)
+    w, h, s = 480, 270, 128
+    cam, light, glob = default_inputs(w, h, use_shadows=0)
+    g = render_gpu(small_scene, cam, light, glob, abi.PASS_LIGHT_DEBUG, w, h, s)
+    o = render_oracle(small_scene, cam, light, glob, abi.PASS_LIGHT_DEBUG, w, h, s)
+    assert_parity(g, o)
+
+
+def test_cube_config1_full_size():
+    # BASELINE configs[0]: Cube.glb at 1280x720, PBS only
+    sc, cam, light, glob, passes, w, h, s = cube_config1(1280, 720)
+    g = render_gpu(sc, cam, light, glob, passes, w, h, s)
+    o = render_oracle(sc, cam, light, glob, passes, w, h, s)
+    m = assert_parity(g, o)
+    assert (g["vis"] != 0xFFFFFFFF).sum() > 20000, m
+
+
+@pytest.mark.parametrize("name,maker", [("cube_frame_160x90", lambda: cube_config1(160, 90)),
+                                        ("standin_frame_192x108", lambda: standin_small(192, 108))])
+def test_committed_golden_frames(name, maker):
+    sc, cam, light, glob, passes, w, h, s = maker()
+    g = render_gpu(sc, cam, light, glob, passes, w, h, s)
+    gold = np.load(os.path.join(GOLDEN, name + ".npz"))
+    o = dict(vis=gold["visibility"], depth=gold["depth"], color=gold["color"])
+    assert_parity(dict(vis=g["vis"], depth=g["depth"], color=g["color"]), o)
+    if passes & abi.PASS_SHADOWS:
+        assert np.array_equal(g["shadow"][3], gold["shadow_face3"])
+
+
+@pytest.mark.parametrize("w,h,s", [(333, 207, 200), (64, 64, 64), (65, 17, 96), (1, 1, 1)])
+def test_ragged_target_sizes(tiny_scene, w, h, s):
+    cam, light, glob = default_inputs(w, h)
+    g = render_gpu(tiny_scene, cam, light, glob, abi.PASS_ALL, w, h, s)
+    o = render_oracle(tiny_scene, cam, light, glob, abi.PASS_ALL, w, h, s, threads=4)
+    assert_parity(g, o)
+
+
+POSES = [
+    ((-1400.0, 40.0, -600.0), 20.0, 35.0),     # corner of the hall, looking up and across
+    ((0.0, 900.0, 0.0), -80.0, 0.0),           # from the ceiling straight down (fog top face fills the view)
+    ((-500.0, 30.0, 0.0), 0.0, 0.0),           # inside the fog box: no fog fragments
+    ((-1250.0, 100.0, -262.0), 0.0, 90.0),     # inside a column: near-plane clipping everywhere
+    ((1400.0, 500.0, 0.0), -10.0, 180.0),      # upper tier looking back down the nave
+    ((-500.0, 150.0, 0.0), 0.0, 180.0),        # facing the near wall
+]
+
+
+@pytest.mark.parametrize("pose", POSES)
+def test_camera_poses(small_scene, pose):
+    w, h, s = 320, 180, 256
+    cam, light, glob = default_inputs(w, h, pose=pose)
+    g = render_gpu(small_scene, cam, light, glob, abi.PASS_ALL, w, h, s)
+    o = render_oracle(small_scene, cam, light, glob, abi.PASS_ALL, w, h, s)
+    assert_parity(g, o)
+
+
+@pytest.mark.parametrize("t", [0.0, 7.3, 123.0])
+def test_light_animation_times(tiny_scene, t):
+    # t = 0 is the black light (|sin 0| = 0, state.rs:615-617); larger t moves light and fog drift
+    w, h, s = 256, 144, 256
+    cam, light, glob = default_inputs(w, h, t=t)
+    g = render_gpu(tiny_scene, cam, light, glob, abi.PASS_ALL, w, h, s)
+    o = render_oracle(tiny_scene, cam, light, glob, abi.PASS_ALL, w, h, s, threads=8)
+    assert_parity(g, o)
+
+
+def _quad(x0, x1, y0, y1, z, uv=1.0):
+    v = np.zeros((4, 14), np.float32)
+    v[:, 0:3] = [[x0, y0, z], [x1, y0, z], [x1, y1, z], [x0, y1, z]]
+    v[:, 3:5] = [[0, 0], [uv, 0], [uv, uv], [0, uv]]
+    v[:, 5:8] = [0, 0, 1]
+    v[:, 8:11] = [1, 0, 0]
+    v[:, 11:14] = [0, 1, 0]
+    return v, np.array([0, 1, 2, 0, 2, 3], np.uint32)
+
+
+def blend_order_scene(order):
+    """Opaque back wall plus three overlapping translucent / cut-out quads drawn in `order`
+    (far-to-near, near-to-far or mixed): the final colour depends on which fragments passed
+    the depth test when they were drawn (state.rs:466 blending + depth writes, no sorting)."""
+    rng = np.random.default_rng(3)
+    tex = []
+    for color, alpha in (((200, 60, 40), 255), ((40, 200, 60), 128), ((40, 60, 220), 64), ((230, 230, 60), None)):
+        a = np.empty((16, 16, 4), np.uint8)
+        a[..., :3] = color
+        a[..., 3] = alpha if alpha is not None else np.where(rng.random((16, 16)) > 0.5, 255, 0)
+        flat = np.zeros((16, 16, 4), np.uint8)
+        flat[..., :] = (128, 128, 255, 255)
+        mr = np.zeros((16, 16, 4), np.uint8)
+        mr[..., 1], mr[..., 3] = 180, 255
+        tex += [(a, True), (flat, False), (mr, False)]
+    mats = [scene.Material(3 * i, 3 * i + 1, 3 * i + 2, 1.0, 1.0) for i in range(4)]
+    quads = {
+        0: (_quad(-300, 300, -200, 200, -100.0), 0),      # opaque wall
+        1: (_quad(-200, 100, -150, 100, -50.0, 3.0), 1),  # alpha 128
+        2: (_quad(-50, 250, -100, 150, 0.0, 3.0), 2),     # alpha 64, nearest
+        3: (_quad(-150, 150, -50, 180, -25.0, 5.0), 3),   # cut-out, bilinear taps give fractional alpha
+    }
+    meshes = [scene.Mesh(quads[k][0][0], quads[k][0][1], quads[k][1]) for k in order]
+    cube = scene.cube_model()
+    return scene.Scene(tex, scene.Model(meshes, mats), cube, scene.cube_model(),
+                       abi.instance_raw((0.0, 0.0, 0.0)), abi.instance_raw((0.0, -500.0, 0.0), (1, 0, 0, 0), (10.0, 10.0, 10.0)))
+
+
+@pytest.mark.parametrize("order", [(0, 1, 3, 2), (2, 3, 1, 0), (1, 0, 2, 3), (3, 2, 0, 1)])
+def test_ordered_blending_follows_draw_order(order):
+    w, h, s = 320, 240, 64
+    sc = blend_order_scene(order)
+    cam = abi.camera_uniform((0.0, 0.0, 500.0), 0.0, -90.0, 55.0, w, h)  # looking down -z
+    light = abi.light_uniform((0.0, 100.0, 300.0), (1.0, 1.0, 1.0, 250000.0))
+    glob = abi.global_uniforms(1.0, 0)
+    g = render_gpu(sc, cam, light, glob, abi.PASS_LIGHT_DEBUG, w, h, s)
+    o = render_oracle(sc, cam, light, glob, abi.PASS_LIGHT_DEBUG, w, h, s, threads=2)
+    assert_parity(g, o)
+    assert np.array_equal(g["color"], o["color"])  # blending is 8-bit round trips: exact
+    assert o["counters"]["blended_lt1"] > 1000
+    assert (o["color"][..., 3] < 255).any()  # alpha is blended too (pass.rs:79-82)
+
+
+def test_draw_orders_give_different_images():
+    w, h, s = 160, 120, 64
+    cam = abi.camera_uniform((0.0, 0.0, 500.0), 0.0, -90.0, 55.0, w, h)
+    light = abi.light_uniform((0.0, 100.0, 300.0), (1.0, 1.0, 1.0, 250000.0))
+    glob = abi.global_uniforms(1.0, 0)
+    a = render_gpu(blend_order_scene((0, 1, 3, 2)), cam, light, glob, abi.PASS_LIGHT_DEBUG, w, h, s)["color"]
+    b = render_gpu(blend_order_scene((2, 3, 1, 0)), cam, light, glob, abi.PASS_LIGHT_DEBUG, w, h, s)["color"]
+    assert (a != b).any()
+
+
+def test_degenerate_and_extreme_triangles():
+    """Zero-area, duplicated-vertex, sliver, screen-filling and far-outside triangles, a
+    triangle through the camera, and NaN tangents (a GLB without TANGENT, mesh.rs:67-69)."""
+    w, h, s = 200, 150, 64
+    v = np.zeros((0, 14), np.float32)
+    tris = [
+        [(0, 0, -100), (0, 0, -100), (0, 0, -100)],                  # point
+        [(-50, 0, -100), (50, 0, -100), (0, 0, -100)],               # collinear
+        [(-1e5, -1e5, -300), (1e5, -1e5, -300), (0, 1e5, -300)],     # covers everything, guard-band clipped
+        [(-40, -40, -200), (40, -40, -200), (0, 1e-4, -200)],        # sliver
+        [(-30, -30, 50), (30, -30, -400), (0, 40, -400)],            # crosses the camera plane
+        [(1e4, 1e4, -50), (1.1e4, 1e4, -50), (1e4, 1.1e4, -50)],     # far outside the frustum
+        [(-20, -20, -150), (20, -20, -150), (0, 20, -150)],          # ordinary, NaN tangents below
+        [(-20, -20, -2990), (20, -20, -3010), (0, 20, -2990)],       # crosses the far plane
+    ]
+    verts, idx = [], []
+    for t in tris:
+        for p in t:
+            row = np.zeros(14, np.float32)
+            row[0:3] = p
+            row[3:5] = (p[0] * 0.01, p[1] * 0.01)
+            row[5:8] = (0, 0, 1)
+            row[8:11] = (1, 0, 0)
+            row[11:14] = (0, 1, 0)
+            verts.append(row)
+        idx += [len(verts) - 3, len(verts) - 2, len(verts) - 1]
+    v = np.array(verts, np.float32)
+    v[18:21, 8:14] = np.nan
+    sc0 = blend_order_scene((0,))
+    sc = scene.Scene(sc0.textures, scene.Model([scene.Mesh(v, np.array(idx, np.uint32), 0)], sc0.geometry.materials),
+                     scene.cube_model(), scene.cube_model(), abi.instance_raw((0.0, 0.0, 0.0)),
+                     abi.instance_raw((0.0, 0.0, -200.0), (1, 0, 0, 0), (60.0, 20.0, 60.0)))
+    cam = abi.camera_uniform((0.0, 0.0, 0.0), 0.0, -90.0, 55.0, w, h)
+    light = abi.light_uniform((10.0, 40.0, -100.0), (1.0, 0.9, 0.8, 250000.0))
+    glob = abi.global_uniforms(3.0, 1)
+    g = render_gpu(sc, cam, light, glob, abi.PASS_ALL, w, h, s)
+    o = render_oracle(sc, cam, light, glob, abi.PASS_ALL, w, h, s, threads=2)
+    assert_parity(g, o)
+    assert (o["vis"] != 0xFFFFFFFF).mean() > 0.9  # the huge triangle was clipped, not dropped
+
+
+def test_resize_and_scene_reuse(tiny_scene):
+    cam, light, glob = default_inputs(200, 120)
+    r = abi.Renderer(200, 120, 128)
+    r.upload_scene(tiny_scene)
+    r.render_frame(cam, light, glob, abi.PASS_ALL)
+    a = r.read_color()
+    r.resize(0, 0)  # ignored like state.rs:576
+    r.resize(320, 200)
+    cam2, _, _ = default_inputs(320, 200)
+    r.render_frame(cam2, light, glob, abi.PASS_ALL)
+    b = r.read_color()
+    r.resize(200, 120)
+    r.render_frame(cam, light, glob, abi.PASS_ALL)
+    assert np.array_equal(r.read_color(), a) and b.shape == (200, 320, 4)
+    o = render_oracle(tiny_scene, cam2, light, glob, abi.PASS_ALL, 320, 200, 128, threads=4)
+    assert np.array_equal(b, o["color"])
+    r.close()
+
+
+def test_error_paths():
+    r = abi.Renderer(64, 64, 64)
+    cam, light, glob = default_inputs(64, 64)
+    with pytest.raises(abi.WrError) as e:
+        r.render_frame(cam, light, glob, abi.PASS_ALL)
+    assert e.value.code == abi.WR_ERR_NO_SCENE
+    with pytest.raises(abi.WrError):
+        r.upload_material(0, 5, 5, 5, 1.0, 1.0)  # unknown textures
+    tex = np.zeros((4, 4, 4), np.uint8)
+    r.upload_texture(tex, True)
+    r.upload_material(0, 0, 0, 0, 1.0, 1.0)
+    v, i = _quad(-1, 1, -1, 1, 0)
+    with pytest.raises(abi.WrError):
+        r.upload_mesh(0, v, np.array([0, 1, 9], np.uint32), 0)  # index out of range
+    with pytest.raises(abi.WrError):
+        r.upload_mesh(0, v, i, 3)  # unknown material
+    r.close()
+    with pytest.raises(abi.WrError):
+        abi.Renderer(64, 64, 64, tile_rank=2, tile_world=2)
+    with pytest.raises(abi.WrError):
+        abi.Renderer(0, 64, 64)
+
+
+# ------------------------------------------------------------------ full size
+@pytest.fixture(scope="module")
+def full_scene():
+    return scene.sponza_standin(detail=1.0, tex_size=256)
+
+
+def test_full_size_frame_against_oracle(full_scene):
+    """BASELINE configs[2] at its real size: 1920x1080, six 2048^2 shadow faces, fog."""
+    w, h, s = 1920, 1080, 2048
+    cam, light, glob = default_inputs(w, h)
+    g = render_gpu(full_scene, cam, light, glob, abi.PASS_ALL, w, h, s, counting=True)
+    o = render_oracle(full_scene, cam, light, glob, abi.PASS_ALL, w, h, s, threads=16)
+    assert_parity(g, o)
+    assert g["counters"]["fog_noise_evals"] == o["counters"]["fog_noise_evals"]
+
+
+def test_full_size_properties(full_scene):
+    """Size-independent properties at 1920x1080: determinism, pose batch == single frames,
+    shadow reuse == recomputation, bin-sharded rendering == whole-frame rendering."""
+    import torch
+    w, h, s = 1920, 1080, 2048
+    cam, light, glob = default_inputs(w, h)
+    r = abi.Renderer(w, h, s)
+    r.upload_scene(full_scene)
+    r.render_frame(cam, light, glob, abi.PASS_ALL)
+    ref = r.read_color()
+    ref_vis = r.read_visibility()
+    r.render_frame(cam, light, glob, abi.PASS_ALL)
+    assert np.array_equal(r.read_color(), ref) and np.array_equal(r.read_visibility(), ref_vis)
+    # batch of three poses, shadows computed once, frames delivered to device memory
+    cams = [cam, default_inputs(w, h, pose=scene.flythrough_pose(40))[0], default_inputs(w, h, pose=scene.flythrough_pose(300))[0]]
+    frames = torch.zeros((3, h, w, 4), dtype=torch.uint8, device="cuda")
+    r.render_batch(cams, light, glob, abi.PASS_ALL, shadows_every_frame=False, device_frames=frames.data_ptr())
+    r.sync()
+    torch.cuda.synchronize()
+    fr = frames.cpu().numpy()
+    assert np.array_equal(fr[0], ref)
+    for k in (1, 2):
+        r.render_frame(cams[k], light, glob, abi.PASS_ALL)
+        assert np.array_equal(r.read_color(), fr[k])
+    r.close()
+    # screen-bin sharding over 3 contexts, gathered through packed bin buffers
+    world = 3
+    nb = ((w + 63) // 64) * ((h + 63) // 64)
+    per = (nb + world - 1) // world
+    gathered = abi.Renderer(w, h, s)
+    for rank in range(world):
+        rr = abi.Renderer(w, h, s, tile_rank=rank, tile_world=world)
+        rr.upload_scene(full_scene)
+        rr.render_frame(cam, light, glob, abi.PASS_ALL)
+        packed = torch.zeros(per * 64 * 64, dtype=torch.int32, device="cuda")
+        n = rr.pack_owned_bins(packed.data_ptr())
+        rr.sync()
+        assert n == len(range(rank, nb, world))
+        gathered.scatter_bins(packed.data_ptr(), rank, world)
+        gathered.sync()
+        rr.close()
+    assert np.array_equal(gathered.read_color(), ref)
+    gathered.close()

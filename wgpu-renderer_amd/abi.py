@@ -82,6 +82,7 @@ class FrameStats(C.Structure):
         ("ms_shade", C.c_float),
         ("ms_fog", C.c_float),
         ("ms_total", C.c_float),
+        ("profiled_frames", C.c_uint32),
         ("geometry_bin_items", C.c_uint32),
         ("shadow_bin_items", C.c_uint32),
         ("fog_fragments", C.c_uint64),

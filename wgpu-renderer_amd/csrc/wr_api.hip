@@ -89,8 +89,12 @@ struct WrContext {
     uint32_t* d_err = nullptr;  // [0] error bits, [1] geometry bin items, [2] shadow bin items, [3] fog (unused)
 
     bool profiling = false, counting = false;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool ev_valid = false;
+    // Profiling keeps one set of five stage-boundary events per frame in a ring; wr_get_stats
+    // averages the stage times over the frames recorded since profiling was switched on.
+    static constexpr int kEvFrames = 128;
+    hipEvent_t ev[kEvFrames][5] = {};
+    int ev_count = 0;  // frames recorded since wr_set_profiling(1), saturates at kEvFrames
+    int ev_next = 0;
     WrFrameStats stats{};
 };
 
@@ -314,11 +318,12 @@ int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do
     const ModelDev& lm = ctx->dev[WR_MODEL_LIGHT_MARKER];
     const ModelDev& fm = ctx->dev[WR_MODEL_FOG_VOLUME];
     const bool prof = ctx->profiling;
+    hipEvent_t* ev = ctx->ev[ctx->ev_next];
     int rc;
-    if (prof) WR_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    if (prof) WR_HIP(hipEventRecord(ev[0], ctx->stream));
     if (do_shadow && (passes & WR_PASS_SHADOWS))
         if ((rc = shadow_stage(ctx, fc)) != WR_OK) return rc;
-    if (prof) WR_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    if (prof) WR_HIP(hipEventRecord(ev[1], ctx->stream));
 
     // geometry + light marker -> visibility / depth
     WR_HIP(hipMemsetAsync(ctx->geom.counters, 0, ctx->geom.counters_bytes, ctx->stream));
@@ -330,7 +335,7 @@ int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do
         hipLaunchKernelGGL(k_setup_small, grid1(lm.ntris), dim3(256), 0, ctx->stream, lm.pos, lm.idx, lm.ntris, 0,
                            (passes & WR_PASS_LIGHT_DEBUG) ? 1 : 0, g.ntris, ctx->geom.ws, fc);
     if ((rc = bin_and_raster(ctx, ctx->geom, false, fc.tile_rank, fc.tile_world)) != WR_OK) return rc;
-    if (prof) WR_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+    if (prof) WR_HIP(hipEventRecord(ev[2], ctx->stream));
 
     ShadeArgs sa;
     sa.fc = fc; sa.ws = ctx->geom.ws; sa.vis = ctx->d_vis; sa.depth = ctx->d_depth; sa.color = ctx->d_color;
@@ -341,7 +346,7 @@ int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do
     dim3 pg((uint32_t)(ctx->W + 15) / 16, (uint32_t)(ctx->H + 15) / 16, 1);
     if (ctx->counting) hipLaunchKernelGGL(k_shade<true>, pg, dim3(256), 0, ctx->stream, sa);
     else hipLaunchKernelGGL(k_shade<false>, pg, dim3(256), 0, ctx->stream, sa);
-    if (prof) WR_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+    if (prof) WR_HIP(hipEventRecord(ev[3], ctx->stream));
 
     if ((passes & WR_PASS_FOG) && fm.ntris) {
         WR_HIP(hipMemsetAsync(ctx->fog.counters, 0, ctx->fog.counters_bytes, ctx->stream));
@@ -355,8 +360,9 @@ int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do
         else hipLaunchKernelGGL(k_fog<false>, pg, dim3(256), 0, ctx->stream, fa);
     }
     if (prof) {
-        WR_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
-        ctx->ev_valid = true;
+        WR_HIP(hipEventRecord(ev[4], ctx->stream));
+        ctx->ev_next = (ctx->ev_next + 1) % WrContext::kEvFrames;
+        if (ctx->ev_count < WrContext::kEvFrames) ++ctx->ev_count;
     }
     WR_HIP(hipGetLastError());
     return WR_OK;
@@ -400,7 +406,8 @@ int wr_create(const WrConfig* config, WrContext** out_ctx) {
     auto body = [&]() -> int {
         if (config->stream) ctx->stream = (hipStream_t)config->stream;
         else { WR_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
-        for (int i = 0; i < 5; ++i) WR_HIP(hipEventCreate(&ctx->ev[i]));
+        for (int f = 0; f < WrContext::kEvFrames; ++f)
+            for (int i = 0; i < 5; ++i) WR_HIP(hipEventCreate(&ctx->ev[f][i]));
         float tables[768];
         build_tables(tables);
         WR_HIP(hipMalloc(&ctx->d_tables, sizeof(tables)));
@@ -428,7 +435,8 @@ void wr_destroy(WrContext* ctx) {
     free_scene(ctx);
     free_targets(ctx);
     dfree(ctx->d_tables); dfree(ctx->d_counters); dfree(ctx->d_err); dfree(ctx->d_shadow);
-    for (int i = 0; i < 5; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    for (int f = 0; f < WrContext::kEvFrames; ++f)
+        for (int i = 0; i < 5; ++i) if (ctx->ev[f][i]) (void)hipEventDestroy(ctx->ev[f][i]);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -601,7 +609,8 @@ int wr_scatter_bins(WrContext* ctx, const void* device_src, uint32_t rank, uint3
 int wr_set_profiling(WrContext* ctx, int enabled) {
     if (!ctx) return WR_ERR_INVALID_ARGUMENT;
     ctx->profiling = enabled != 0;
-    ctx->ev_valid = false;
+    ctx->ev_count = 0;
+    ctx->ev_next = 0;
     return WR_OK;
 }
 int wr_set_counting(WrContext* ctx, int enabled) {
@@ -614,11 +623,19 @@ int wr_get_stats(WrContext* ctx, WrFrameStats* out) {
     if (!ctx || !out) return WR_ERR_INVALID_ARGUMENT;
     int rc = wr_sync(ctx);
     if (rc != WR_OK) return rc;
-    if (ctx->ev_valid) {
-        float ms[4] = {0, 0, 0, 0};
-        for (int i = 0; i < 4; ++i) WR_HIP(hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]));
-        ctx->stats.ms_shadow = ms[0]; ctx->stats.ms_geometry = ms[1]; ctx->stats.ms_shade = ms[2]; ctx->stats.ms_fog = ms[3];
-        ctx->stats.ms_total = ms[0] + ms[1] + ms[2] + ms[3];
+    if (ctx->ev_count > 0) {
+        double ms[4] = {0, 0, 0, 0};
+        for (int f = 0; f < ctx->ev_count; ++f)
+            for (int i = 0; i < 4; ++i) {
+                float t = 0.0f;
+                WR_HIP(hipEventElapsedTime(&t, ctx->ev[f][i], ctx->ev[f][i + 1]));
+                ms[i] += t;
+            }
+        for (int i = 0; i < 4; ++i) ms[i] /= ctx->ev_count;
+        ctx->stats.ms_shadow = (float)ms[0]; ctx->stats.ms_geometry = (float)ms[1];
+        ctx->stats.ms_shade = (float)ms[2]; ctx->stats.ms_fog = (float)ms[3];
+        ctx->stats.ms_total = (float)(ms[0] + ms[1] + ms[2] + ms[3]);
+        ctx->stats.profiled_frames = (uint32_t)ctx->ev_count;
     }
     unsigned long long c[8];
     WR_HIP(hipMemcpy(c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));

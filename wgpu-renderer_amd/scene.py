@@ -224,7 +224,7 @@ def sponza_standin(detail: float = 1.0, tex_size: int = 1024, n_materials: int =
     from . import abi
 
     rng = np.random.default_rng(seed)
-    k = lambda base: max(2, int(round(base * detail)))       # tessellation along one axis
+    k = lambda base: max(2, int(round(base * detail * 0.9)))  # tessellation along one axis
     kc = lambda base: max(1, int(round(base * np.sqrt(detail))))  # object counts
     off = np.array([-60.0, 0.0, -35.0])  # undo the instance translation
 
@@ -296,12 +296,12 @@ def sponza_standin(detail: float = 1.0, tex_size: int = 1024, n_materials: int =
                 return np.stack([xc + rr * np.cos(th), 70.0 * T, zc + rr * np.sin(th)], axis=2)
             add(12, _surface(vase, k(24), k(12), (2.0, 1.0)))
             for ang in (0.0, np.pi / 3, 2 * np.pi / 3):
-                dx, dz = 70.0 * np.cos(ang), 70.0 * np.sin(ang)
+                dx, dz = 32.0 * np.cos(ang), 32.0 * np.sin(ang)
                 for sgn in (1.0, -1.0):
-                    add(8, _patch((xc - sgn * dx, 60.0, zc - sgn * dz), (2 * sgn * dx, 0, 2 * sgn * dz), (0, 150.0, 0), k(4), k(4), (1.0, 1.0)))
+                    add(8, _patch((xc - sgn * dx, 60.0, zc - sgn * dz), (2 * sgn * dx, 0, 2 * sgn * dz), (0, 85.0, 0), k(4), k(4), (1.0, 1.0)))
     # half-transparent pane across the nave, seen by the reference camera
-    add(9, _patch((350.0, 40.0, 180.0), (0, 0, -360.0), (0, 330.0, 0), k(6), k(6), (1.0, 1.0)))
-    add(9, _patch((350.0, 40.0, -180.0), (0, 0, 360.0), (0, 330.0, 0), k(6), k(6), (1.0, 1.0)))
+    add(9, _patch((350.0, 60.0, 100.0), (0, 0, -200.0), (0, 180.0, 0), k(6), k(6), (1.0, 1.0)))
+    add(9, _patch((350.0, 60.0, -100.0), (0, 0, 200.0), (0, 180.0, 0), k(6), k(6), (1.0, 1.0)))
     # lion-head relief on the far wall: dense bumpy dome
     def lion(S, T):
         th = S * np.pi
