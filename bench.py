@@ -172,6 +172,8 @@ def main():
     step(0)
     st = r.stats()
     fog_frags, noise_evals, shaded = int(st.fog_fragments), int(st.fog_noise_evals), int(st.shaded_fragments)
+    replay_px, replay_slow = int(st.replay_pixels), int(st.replay_slow_pixels)
+    bin_items = (int(st.geometry_bin_items), int(st.shadow_bin_items))
     r.set_counting(False)
 
     for i in range(args.warmup):
@@ -259,6 +261,9 @@ def main():
             "fog_fragments": fog_frags,
             "fog_noise_evals": noise_evals,
             "shaded_fragments": shaded,
+            "ordered_blend_pixels": replay_px,
+            "ordered_blend_slow_pixels": replay_slow,
+            "bin_items": {"geometry": bin_items[0], "shadow": bin_items[1]},
             "roofline": roofline,
             "roofline_hbm_frame": hbm,
             "cpu_baseline": cpu,

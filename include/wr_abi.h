@@ -140,6 +140,7 @@ typedef struct WrFrameStats {
     uint64_t fog_noise_evals;    /* fog_noise evaluations executed (counting mode only) */
     uint64_t shaded_fragments;   /* PBS fragments shaded (counting mode only) */
     uint64_t replay_pixels;      /* pixels that took the ordered-blend path (counting mode only) */
+    uint64_t replay_slow_pixels; /* of those, pixels covered by too many fragments for the fast path */
 } WrFrameStats;
 
 /* ------------------------------------------------------------------ context */

@@ -14,7 +14,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libwr_hip.so")
+LIB_PATH = os.environ.get("WR_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "libwr_hip.so")
 
 WR_OK = 0
 WR_ERR_INVALID_ARGUMENT = -1
@@ -89,6 +89,7 @@ class FrameStats(C.Structure):
         ("fog_noise_evals", C.c_uint64),
         ("shaded_fragments", C.c_uint64),
         ("replay_pixels", C.c_uint64),
+        ("replay_slow_pixels", C.c_uint64),
     ]
 
 

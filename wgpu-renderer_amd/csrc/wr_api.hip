@@ -86,6 +86,7 @@ struct WrContext {
     uint32_t* d_color = nullptr;
     float* d_shadow = nullptr;
     unsigned long long* d_counters = nullptr;
+    uint8_t* d_rp_flag = nullptr;    // [H][W] pixels flagged for ordered blending
     uint32_t* d_err = nullptr;  // [0] error bits, [1] geometry bin items, [2] shadow bin items, [3] fog (unused)
 
     bool profiling = false, counting = false;
@@ -124,7 +125,7 @@ void free_ws(WsAlloc& w) {
 }
 
 int alloc_ws(WrContext* ctx, WsAlloc& w, uint32_t slots, uint32_t ovf_cap, uint32_t items_cap, int bins_x, int bins_y,
-             int layers, uint32_t* err, uint32_t* total_items) {
+             int layers, uint32_t* err, uint32_t* total_items, size_t extra_counters = 0) {
     free_ws(w);
     RasterWS& ws = w.ws;
     ws.slots = slots; ws.ovf_cap = ovf_cap; ws.items_cap = items_cap;
@@ -133,7 +134,7 @@ int alloc_ws(WrContext* ctx, WsAlloc& w, uint32_t slots, uint32_t ovf_cap, uint3
     size_t nb = (size_t)bins_x * bins_y * layers;
     WR_HIP(hipMalloc(&ws.recs, sizeof(Rec) * (size_t)layers * ((size_t)slots + ovf_cap)));
     WR_HIP(hipMalloc(&ws.betas, sizeof(float) * 9 * (size_t)layers * ovf_cap + 64));
-    w.counters_bytes = sizeof(uint32_t) * ((size_t)layers + 2 * nb);
+    w.counters_bytes = sizeof(uint32_t) * ((size_t)layers + 2 * nb + extra_counters);
     WR_HIP(hipMalloc(&w.counters, w.counters_bytes));
     ws.ovf_count = w.counters;
     ws.bin_count = w.counters + layers;
@@ -145,7 +146,7 @@ int alloc_ws(WrContext* ctx, WsAlloc& w, uint32_t slots, uint32_t ovf_cap, uint3
 }
 
 void free_targets(WrContext* c) {
-    dfree(c->d_vis); dfree(c->d_depth); dfree(c->d_color);
+    dfree(c->d_vis); dfree(c->d_depth); dfree(c->d_color); dfree(c->d_rp_flag);
 }
 void free_scene(WrContext* c) {
     for (int m = 0; m < 3; ++m) {
@@ -165,6 +166,8 @@ int alloc_targets(WrContext* ctx) {
     WR_HIP(hipMalloc(&ctx->d_vis, n * 4));
     WR_HIP(hipMalloc(&ctx->d_depth, n * 4));
     WR_HIP(hipMalloc(&ctx->d_color, n * 4));
+    WR_HIP(hipMalloc(&ctx->d_rp_flag, n));
+    WR_HIP(hipMemset(ctx->d_rp_flag, 0, n));
     WR_HIP(hipMemset(ctx->d_color, 0, n * 4));
     return WR_OK;
 }
@@ -221,7 +224,18 @@ int build_scene(WrContext* ctx) {
         if (!descs.empty()) WR_HIP(hipMemcpy(ctx->d_tex, descs.data(), descs.size() * sizeof(TexDesc), hipMemcpyHostToDevice));
     }
     {
-        const std::vector<MatDesc>& mats = ctx->host[WR_MODEL_GEOMETRY].mats;
+        // a material whose base-colour texture has alpha 255 everywhere can only produce alpha 1
+        std::vector<MatDesc>& mats = ctx->host[WR_MODEL_GEOMETRY].mats;
+        std::vector<int> tex_opaque(ctx->tex_host.size(), -1);
+        for (MatDesc& m : mats) {
+            if (tex_opaque[m.base] < 0) {
+                const TexHost& t = ctx->tex_host[m.base];
+                int op = 1;
+                for (size_t i = 3; i < t.px.size(); i += 4) if (t.px[i] != 255) { op = 0; break; }
+                tex_opaque[m.base] = op;
+            }
+            m.opaque = (uint32_t)tex_opaque[m.base];
+        }
         WR_HIP(hipMalloc(&ctx->d_mats, std::max<size_t>(mats.size(), 1) * sizeof(MatDesc)));
         if (!mats.empty()) WR_HIP(hipMemcpy(ctx->d_mats, mats.data(), mats.size() * sizeof(MatDesc), hipMemcpyHostToDevice));
     }
@@ -343,9 +357,15 @@ int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do
     sa.v0 = ctx->vout.v0; sa.v1 = ctx->vout.v1; sa.v2 = ctx->vout.v2; sa.v3 = ctx->vout.v3;
     sa.mats = ctx->d_mats; sa.tex = ctx->d_tex; sa.texels = ctx->d_texels; sa.tables = ctx->d_tables;
     sa.shadow = ctx->d_shadow; sa.counters = ctx->d_counters;
+    sa.rp_flag = ctx->d_rp_flag;
     dim3 pg((uint32_t)(ctx->W + 15) / 16, (uint32_t)(ctx->H + 15) / 16, 1);
-    if (ctx->counting) hipLaunchKernelGGL(k_shade<true>, pg, dim3(256), 0, ctx->stream, sa);
-    else hipLaunchKernelGGL(k_shade<false>, pg, dim3(256), 0, ctx->stream, sa);
+    if (ctx->counting) {
+        hipLaunchKernelGGL(k_shade<true>, pg, dim3(256), 0, ctx->stream, sa);
+        hipLaunchKernelGGL(k_replay<true>, pg, dim3(256), 0, ctx->stream, sa);
+    } else {
+        hipLaunchKernelGGL(k_shade<false>, pg, dim3(256), 0, ctx->stream, sa);
+        hipLaunchKernelGGL(k_replay<false>, pg, dim3(256), 0, ctx->stream, sa);
+    }
     if (prof) WR_HIP(hipEventRecord(ev[3], ctx->stream));
 
     if ((passes & WR_PASS_FOG) && fm.ntris) {
@@ -640,7 +660,7 @@ int wr_get_stats(WrContext* ctx, WrFrameStats* out) {
     unsigned long long c[8];
     WR_HIP(hipMemcpy(c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
     ctx->stats.fog_fragments = c[0]; ctx->stats.fog_noise_evals = c[1];
-    ctx->stats.shaded_fragments = c[2]; ctx->stats.replay_pixels = c[3];
+    ctx->stats.shaded_fragments = c[2]; ctx->stats.replay_pixels = c[3]; ctx->stats.replay_slow_pixels = c[4];
     *out = ctx->stats;
     return WR_OK;
 }

@@ -375,7 +375,7 @@ WR_HD uint32_t blend_pack(const ColorTables& ct, uint32_t dst, V4 src, bool blen
 // ---------------------------------------------------------------------------------------
 // Material textures: texture.rs:118-126 (Repeat, mag Linear, min Nearest, one level).
 struct TexDesc { uint32_t offset, w, h, srgb; };
-struct MatDesc { uint32_t base, normal, mr; float metallic, roughness; uint32_t pad0, pad1, pad2; };
+struct MatDesc { uint32_t base, normal, mr; float metallic, roughness; uint32_t opaque /* base-colour alpha is 255 everywhere */, pad1, pad2; };
 
 WR_HD int wrapi(int i, int n) { i %= n; return i < 0 ? i + n : i; }
 WR_HD int clampi(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
@@ -524,7 +524,11 @@ WR_HD V4 fs_pbr(const FrameConsts& fc, const ShadowMap& sm, const uint32_t* texe
     float light_dist = length3(lp - v3(in.wpos.x, in.wpos.y, in.wpos.z));
     float att = 1.0f / (1.0f + light_dist * light_dist);
     V3 direct = (v3(fc.light_color[0], fc.light_color[1], fc.light_color[2]) * fc.light_color[3]) * att;
+#if defined(WR_ABLATE) && (WR_ABLATE & 2)
+    float in_light = 0.64f;
+#else
     float in_light = sample_direct_light(fc, sm, in.wpos);
+#endif
     if (in_light > 0.0f) {
         V3 view_dir = normalize3(in.tview - in.tpos);
         V3 half_dir = normalize3(view_dir + light_dir);

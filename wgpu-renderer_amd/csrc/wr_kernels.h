@@ -342,7 +342,8 @@ struct ShadeArgs {
     const uint32_t* texels;
     const float* tables;
     const float* shadow;
-    unsigned long long* counters;  // [0] fog fragments [1] noise evals [2] shaded fragments [3] replay pixels
+    unsigned long long* counters;  // [0] fog fragments [1] noise evals [2] shaded fragments [3] replay pixels [4] slow-path pixels
+    uint8_t* rp_flag;              // [H][W] 1 where the pixel needs ordered blending
 };
 
 // Interpolates the VertexOutput of one fragment and runs pbr.wgsl's fs_main on it.
@@ -443,6 +444,8 @@ __device__ __attribute__((noinline)) uint32_t replay_pixel(const ShadeArgs& a, i
     return col;
 }
 
+constexpr int kReplayK = 16;  // covering fragments kept per pixel before the slow path
+
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
     // 16x16 pixels per workgroup, each wavefront an 8x8 block
@@ -450,13 +453,12 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
     const int px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
     const int py = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
     if (px >= a.fc.W || py >= a.fc.H) return;
-    if (a.fc.tile_world > 1) {
-        int b = (py / kBin) * a.ws.bins_x + (px / kBin);
-        if ((b % a.fc.tile_world) != a.fc.tile_rank) return;
-    }
+    const int bin = (py / kBin) * a.ws.bins_x + (px / kBin);
+    if (a.fc.tile_world > 1 && (bin % a.fc.tile_world) != a.fc.tile_rank) return;
     const size_t pi = (size_t)py * a.fc.W + px;
     const uint32_t id = a.vis[pi];
     ColorTables ct{a.tables};
+    a.rp_flag[pi] = 0;
     if (id == kVisNone) { a.color[pi] = 0xFF000000u; return; }  // clear colour (0,0,0,1), state.rs:696-701
     const uint32_t tri = id >> 3;
     if (tri >= a.ntris_geom) {  // light marker, light_debug.wgsl:23-26
@@ -471,12 +473,145 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
     edge_eval(e, px, py, E);
     V4 src = shade_fragment(a, r, beta, e, tri, px, py, E);
     if (COUNT) atomicAdd(&a.counters[2], 1ull);
-    uint32_t col;
     if (src.w == 1.0f) {
-        col = blend_pack(ct, 0u, src, false);  // alpha 1 replaces whatever was blended before
+        a.color[pi] = blend_pack(ct, 0u, src, false);  // alpha 1 replaces whatever was blended before
     } else {
+        // the front-most fragment is not opaque: this pixel's colour depends on draw order;
+        // flag it for the ordered-blend kernel
         if (COUNT) atomicAdd(&a.counters[3], 1ull);
-        col = replay_pixel(a, px, py);
+#if defined(WR_ABLATE) && (WR_ABLATE & 1)
+        a.color[pi] = blend_pack(ct, 0xFF000000u, src, true);
+#else
+        a.rp_flag[pi] = 1;
+#endif
+    }
+}
+
+// Compact per-triangle data for the ordered-blend kernel, staged in LDS.
+struct ReplayRec {
+    int32_t A[3], B[3];
+    int32_t tlb;      // bit i set: edge i is not top-left
+    uint32_t id;
+    int64_t C[3];
+    float z0, dz1, dz2, inv2A;
+    uint32_t bbmin, bbmax;
+};
+static_assert(sizeof(ReplayRec) == 80, "ReplayRec layout");
+
+// Ordered blending for the pixels k_shade flagged; one workgroup per 16x16 pixel block, one
+// thread per pixel.  Pass 1 walks the triangle list of the block's bin in chunks of 256:
+// every thread fetches one record, records whose bounding box misses the block are
+// dropped, the rest are compacted into LDS, and then all lanes test the same staged record
+// at once against their own pixel, collecting the fragments that cover it.  Sorted by
+// triangle id these give the draw order, and a running minimum over depth gives the
+// fragments that passed the depth test when drawn.  Pass 2 shades and blends those,
+// starting at the last one whose material cannot be translucent (it replaced everything
+// under it).  Pixels covered by more than kReplayK fragments take replay_pixel.
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_replay(ShadeArgs a) {
+    __shared__ ReplayRec srec[256];
+    __shared__ uint32_t cid[kReplayK][256];
+    __shared__ float cz[kReplayK][256];
+    __shared__ uint32_t s_m;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int bx0 = blockIdx.x * 16, by0 = blockIdx.y * 16;
+    const int px = bx0 + (wave & 1) * 8 + (lane & 7);
+    const int py = by0 + (wave >> 1) * 8 + (lane >> 3);
+    const RasterWS& ws = a.ws;
+    const int bin = (by0 / kBin) * ws.bins_x + (bx0 / kBin);
+    if (a.fc.tile_world > 1 && (bin % a.fc.tile_world) != a.fc.tile_rank) return;
+    const bool inside = px < a.fc.W && py < a.fc.H;
+    const size_t pi = (size_t)py * a.fc.W + px;
+    const bool active = inside && a.rp_flag[pi] != 0;
+    if (!__syncthreads_or(active ? 1 : 0)) return;
+    const int bx1 = imin(bx0 + 15, a.fc.W - 1), by1 = imin(by0 + 15, a.fc.H - 1);
+    const uint32_t n = ws.bin_count[bin], off = ws.bin_offset[bin];
+    ColorTables ct{a.tables};
+    const int32_t sx = px * 256 + 128, sy = py * 256 + 128;
+    int cnt = 0;
+    for (uint32_t c0 = 0; c0 < n; c0 += 256) {
+        if (tid == 0) s_m = 0;
+        __syncthreads();
+        if (c0 + tid < n && off + c0 + tid < ws.items_cap) {
+            const Rec* rp = &ws.recs[ws.bin_items[off + c0 + tid]];
+            uint32_t bbmin = rp->bbmin, bbmax = rp->bbmax;
+            if (!((int)(bbmin & 0xffffu) > bx1 || (int)(bbmax & 0xffffu) < bx0 || (int)(bbmin >> 16) > by1 || (int)(bbmax >> 16) < by0)) {
+                Rec r = load_rec(rp);
+                Edges e;
+                make_edges(r, e);
+                if (!box_rejected(e, bx0, by0, bx1, by1)) {
+                    ReplayRec& s = srec[atomicAdd(&s_m, 1u)];
+                    for (int i = 0; i < 3; ++i) { s.A[i] = e.A[i]; s.B[i] = e.B[i]; s.C[i] = e.C[i]; }
+                    s.tlb = (e.tlb[0] & 1) | (e.tlb[1] & 2) | (e.tlb[2] & 4);
+                    s.id = r.id; s.z0 = r.z0; s.dz1 = r.dz1; s.dz2 = r.dz2; s.inv2A = r.inv2A;
+                    s.bbmin = r.bbmin; s.bbmax = r.bbmax;
+                }
+            }
+        }
+        __syncthreads();
+        const int m = (int)s_m;
+        if (active) {
+            for (int j = 0; j < m; ++j) {
+                const ReplayRec& s = srec[j];
+                if (px < (int)(s.bbmin & 0xffffu) || px > (int)(s.bbmax & 0xffffu) || py < (int)(s.bbmin >> 16) || py > (int)(s.bbmax >> 16)) continue;
+                int64_t E0 = (int64_t)s.A[0] * sx + (int64_t)s.B[0] * sy + s.C[0];
+                int64_t E1 = (int64_t)s.A[1] * sx + (int64_t)s.B[1] * sy + s.C[1];
+                int64_t E2 = (int64_t)s.A[2] * sx + (int64_t)s.B[2] * sy + s.C[2];
+                if (((E0 - (s.tlb & 1)) | (E1 - ((s.tlb >> 1) & 1)) | (E2 - ((s.tlb >> 2) & 1))) < 0) continue;
+                float l1 = (float)E1 * s.inv2A, l2 = (float)E2 * s.inv2A;
+                float z = (s.z0 + l1 * s.dz1) + l2 * s.dz2;
+                z = fminf(fmaxf(z, 0.0f), 1.0f);
+                if (cnt < kReplayK) { cid[cnt][tid] = s.id; cz[cnt][tid] = z; }
+                ++cnt;
+            }
+        }
+        __syncthreads();
+    }
+    if (!active) return;  // no barrier below this point
+    if (cnt > kReplayK) {
+        if (COUNT) atomicAdd(&a.counters[4], 1ull);
+        a.color[pi] = replay_pixel(a, px, py);
+        return;
+    }
+    // draw order = ascending id (insertion sort; cnt is small)
+    for (int i = 1; i < cnt; ++i) {
+        uint32_t ki = cid[i][tid];
+        float zi = cz[i][tid];
+        int j = i - 1;
+        while (j >= 0 && cid[j][tid] > ki) { cid[j + 1][tid] = cid[j][tid]; cz[j + 1][tid] = cz[j][tid]; --j; }
+        cid[j + 1][tid] = ki; cz[j + 1][tid] = zi;
+    }
+    // fragments that passed depth test Less at draw time, compacted in place
+    int np = 0, start = 0;
+    float d = 1.0f;
+    for (int i = 0; i < cnt; ++i) {
+        float z = cz[i][tid];
+        if (z < d) {
+            d = z;
+            uint32_t id = cid[i][tid];
+            uint32_t tri = id >> 3;
+            if (tri >= a.ntris_geom || a.mats[a.tri_mat[tri]].opaque) start = np;
+            cid[np][tid] = id;
+            ++np;
+        }
+    }
+    uint32_t col = 0xFF000000u;
+    for (int k = start; k < np; ++k) {
+        uint32_t id = cid[k][tid];
+        uint32_t tri = id >> 3;
+        if (tri >= a.ntris_geom) {
+            col = blend_pack(ct, col, V4{a.fc.light_color[0], a.fc.light_color[1], a.fc.light_color[2], 1.0f}, false);
+            continue;
+        }
+        const float* beta;
+        Rec r = fetch_rec(ws, id, beta);
+        Edges e;
+        make_edges(r, e);
+        int64_t E[3];
+        edge_eval(e, px, py, E);
+        V4 src = shade_fragment(a, r, beta, e, tri, px, py, E);
+        col = blend_pack(ct, col, src, true);
     }
     a.color[pi] = col;
 }
