@@ -87,6 +87,8 @@ struct WrContext {
     float* d_shadow = nullptr;
     unsigned long long* d_counters = nullptr;
     uint8_t* d_rp_flag = nullptr;    // [H][W] pixels flagged for ordered blending
+    uint32_t* d_fog_pixel = nullptr; // [W*H] fog march work items: pixel index
+    float4* d_fog_ray = nullptr;     // [W*H] ray origin + max_fog_depth
     uint32_t* d_err = nullptr;  // [0] error bits, [1] geometry bin items, [2] shadow bin items, [3] fog (unused)
 
     bool profiling = false, counting = false;
@@ -146,7 +148,7 @@ int alloc_ws(WrContext* ctx, WsAlloc& w, uint32_t slots, uint32_t ovf_cap, uint3
 }
 
 void free_targets(WrContext* c) {
-    dfree(c->d_vis); dfree(c->d_depth); dfree(c->d_color); dfree(c->d_rp_flag);
+    dfree(c->d_vis); dfree(c->d_depth); dfree(c->d_color); dfree(c->d_rp_flag); dfree(c->d_fog_pixel); dfree(c->d_fog_ray);
 }
 void free_scene(WrContext* c) {
     for (int m = 0; m < 3; ++m) {
@@ -167,6 +169,8 @@ int alloc_targets(WrContext* ctx) {
     WR_HIP(hipMalloc(&ctx->d_depth, n * 4));
     WR_HIP(hipMalloc(&ctx->d_color, n * 4));
     WR_HIP(hipMalloc(&ctx->d_rp_flag, n));
+    WR_HIP(hipMalloc(&ctx->d_fog_pixel, n * 4));
+    WR_HIP(hipMalloc(&ctx->d_fog_ray, n * sizeof(float4)));
     WR_HIP(hipMemset(ctx->d_rp_flag, 0, n));
     WR_HIP(hipMemset(ctx->d_color, 0, n * 4));
     return WR_OK;
@@ -376,8 +380,16 @@ int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do
         fa.fc = fc; fa.ws = ctx->fog.ws; fa.pos = fm.pos; fa.idx = fm.idx; fa.ntris = fm.ntris;
         fa.depth = ctx->d_depth; fa.color = ctx->d_color; fa.shadow = ctx->d_shadow; fa.tables = ctx->d_tables;
         fa.counters = ctx->d_counters;
-        if (ctx->counting) hipLaunchKernelGGL(k_fog<true>, pg, dim3(256), 0, ctx->stream, fa);
-        else hipLaunchKernelGGL(k_fog<false>, pg, dim3(256), 0, ctx->stream, fa);
+        // the fog workspace has one bin, so its bin_count word is free: it counts march items
+        fa.item_count = ctx->fog.ws.bin_count; fa.item_pixel = ctx->d_fog_pixel; fa.item_ray = ctx->d_fog_ray;
+        dim3 mg((uint32_t)(((size_t)ctx->W * ctx->H + 63) / 64), 1, 1);
+        if (ctx->counting) {
+            hipLaunchKernelGGL(k_fog_setup<true>, pg, dim3(256), 0, ctx->stream, fa);
+            hipLaunchKernelGGL(k_fog_march<true>, mg, dim3(64), 0, ctx->stream, fa);
+        } else {
+            hipLaunchKernelGGL(k_fog_setup<false>, pg, dim3(256), 0, ctx->stream, fa);
+            hipLaunchKernelGGL(k_fog_march<false>, mg, dim3(64), 0, ctx->stream, fa);
+        }
     }
     if (prof) {
         WR_HIP(hipEventRecord(ev[4], ctx->stream));

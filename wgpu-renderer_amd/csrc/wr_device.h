@@ -80,9 +80,13 @@ inline void mat4_mul_mat4(const float* a, const float* b, float* out) {  // out 
 // scheme: octant j from x*4/pi, three-constant reduction, one of two cubic-in-z
 // polynomials; the reduction and Horner steps are fused multiply-adds.  |x| >= 2^30 -> 0.
 WR_HD float wr_sin(float x) {
-    uint32_t sign = f2u(x) & 0x80000000u;
     float ax = fabsf(x);
-    if (!(ax < 1073741824.0f)) return 0.0f;
+    // Branch-free range guard: an out-of-range (or NaN) argument is replaced by +0 on entry,
+    // for which the arithmetic below yields +0, so the eight hashes of one lattice cell stay
+    // in one basic block and the scheduler can interleave their dependent chains.
+    bool in_range = ax < 1073741824.0f;
+    ax = in_range ? ax : 0.0f;
+    uint32_t sign = in_range ? (f2u(x) & 0x80000000u) : 0u;
     float y = ax * 1.27323954473516f;
     int j = (int)y;
     j = (j + 1) & ~1;
@@ -610,13 +614,11 @@ WR_HD V2 ray_march(const FrameConsts& fc, V3 origin, V3 dir, float max_depth, in
 // fog.wgsl:118-123
 WR_HD float depth_to_linear(float depth, float zn, float zf) { return (zn * zf) / (zf + depth * (zn - zf)); }
 
-// fog.wgsl:125-166, ray_march_fog 87-116 inlined.  depth_tex is the geometry depth texture
-// (sampler texture.rs:59-72: ClampToEdge, Linear, no compare).
-WR_HD V4 fs_fog(const FrameConsts& fc, const ShadowMap& sm, const float* depth_tex, V3 origin, float frag_z,
-                int px, int py, uint32_t& evals) {
-    V3 cam = v3(fc.cam_pos[0], fc.cam_pos[1], fc.cam_pos[2]);
-    V3 lp = v3(fc.light_pos[0], fc.light_pos[1], fc.light_pos[2]);
-    V3 direction = normalize3(origin - cam);
+// fog.wgsl:125-136: the part of fs_main before the march.  Returns max_fog_depth; a value
+// <= 0 means the shader returns vec4(0), which blends to an unchanged destination.
+// depth_tex is the geometry depth texture (sampler texture.rs:59-72: ClampToEdge, Linear,
+// no compare).
+WR_HD float fog_max_depth(const FrameConsts& fc, const float* depth_tex, float frag_z, int px, int py) {
     float volume_depth = depth_to_linear(frag_z, fc.planes[0], fc.planes[1]);
     float u = ((float)px + 0.5f) / fc.planes[2], v = ((float)py + 0.5f) / fc.planes[3];
     float x = guard_coord(u * (float)fc.W - 0.5f), y = guard_coord(v * (float)fc.H - 0.5f);
@@ -628,9 +630,15 @@ WR_HD V4 fs_fog(const FrameConsts& fc, const ShadowMap& sm, const float* depth_t
     float t01 = depth_tex[(size_t)j1 * fc.W + i0], t11 = depth_tex[(size_t)j1 * fc.W + i1];
     float gd = lerpf(lerpf(t00, t10, fx), lerpf(t01, t11, fx), fy);
     float geometry_depth = depth_to_linear(gd, fc.planes[0], fc.planes[1]);
-    float max_fog_depth = geometry_depth - volume_depth;
-    if (max_fog_depth <= 0.0f) return V4{0.0f, 0.0f, 0.0f, 0.0f};
+    return geometry_depth - volume_depth;
+}
 
+// fog.wgsl:127-128,138-165 (ray_march_fog 87-116 inlined): the march and the fog colour for
+// a fragment whose max_fog_depth is positive.
+WR_HD V4 fog_march_shade(const FrameConsts& fc, const ShadowMap& sm, V3 origin, float max_fog_depth, uint32_t& evals) {
+    V3 cam = v3(fc.cam_pos[0], fc.cam_pos[1], fc.cam_pos[2]);
+    V3 lp = v3(fc.light_pos[0], fc.light_pos[1], fc.light_pos[2]);
+    V3 direction = normalize3(origin - cam);
     V2 fm = ray_march(fc, origin, direction, max_fog_depth, 30, 5.0f, 2.0f, evals);
     float fog_density = fm.x, fog_depth = fm.y;
     V3 fog_end = origin + direction * fog_depth;

@@ -628,63 +628,127 @@ struct FogArgs {
     const float* shadow;
     const float* tables;
     unsigned long long* counters;
+    uint32_t* item_count;  // march work items appended this frame
+    uint32_t* item_pixel;  // [W*H] pixel index of each item
+    float4* item_ray;      // [W*H] ray origin xyz + max_fog_depth
 };
 
-// Fog pass, state.rs:763-804: every front-facing fog-volume fragment that passes the depth
-// test runs fog.wgsl's fs_main and is blended over the colour target, in draw order.
+// One fog fragment: interpolate the world position, run the pre-march part of fog.wgsl's
+// fs_main.  Returns false if the fragment fails the depth test.
+__device__ inline bool fog_fragment(const FogArgs& a, const Rec& r, const float* beta, uint32_t tri, int px, int py,
+                                    float zbuf, V3& origin, float& max_depth) {
+    Edges e;
+    make_edges(r, e);
+    int64_t E[3];
+    edge_eval(e, px, py, E);
+    if (!edges_inside(e, E)) return false;
+    float z = depth_at(r, E);
+    if (!(z < zbuf)) return false;  // depth test Less, no depth write (state.rs:497-502)
+    float B[3];
+    bary_at(r, beta, E, B);
+    V4 w[3];
+    for (int k = 0; k < 3; ++k) {
+        float4 p = a.pos[a.idx[3 * tri + k]];
+        w[k] = mat4_mul(a.fc.model_fog, V4{p.x, p.y, p.z, 1.0f});
+    }
+    origin = v3(ip(B, w[0].x, w[1].x, w[2].x), ip(B, w[0].y, w[1].y, w[2].y), ip(B, w[0].z, w[1].z, w[2].z));
+    max_depth = fog_max_depth(a.fc, a.depth, z, px, py);
+    return true;
+}
+
+// Fog pass, part 1 (state.rs:763-804): rasterises the fog volume per pixel.  A pixel with
+// exactly one fog fragment (always the case for a convex volume) whose march is not
+// empty becomes a work item for k_fog_march, appended with one atomic per wavefront; a
+// pixel with several fragments is finished here, in draw order.
 template <bool COUNT>
-__global__ __launch_bounds__(256) void k_fog(FogArgs a) {
+__global__ __launch_bounds__(256) void k_fog_setup(FogArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
     const int py = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    if (px >= a.fc.W || py >= a.fc.H) return;
-    if (a.fc.tile_world > 1) {
+    bool live = px < a.fc.W && py < a.fc.H;
+    if (live && a.fc.tile_world > 1) {
         int b = (py / kBin) * ((a.fc.W + kBin - 1) / kBin) + (px / kBin);
-        if ((b % a.fc.tile_world) != a.fc.tile_rank) return;
+        live = (b % a.fc.tile_world) == a.fc.tile_rank;
     }
     const size_t pi = (size_t)py * a.fc.W + px;
-    const float zbuf = a.depth[pi];
-    ColorTables ct{a.tables};
-    ShadowMap sm{a.shadow, a.fc.S};
-    uint32_t col = a.color[pi];
-    bool touched = false;
-    for (uint32_t t = 0; t < a.ntris; ++t) {
-        Rec slot = load_rec(&a.ws.recs[t]);
-        if (slot.id == kRecInvalid) continue;
-        uint32_t first = t, count = 1;
-        if (slot.id == kRecClippedParent) { first = (uint32_t)slot.X0; count = (uint32_t)slot.Y0; }
-        for (uint32_t s = 0; s < count; ++s) {
-            uint32_t ri = first + s;
-            Rec r = (slot.id == kRecClippedParent) ? load_rec(&a.ws.recs[ri]) : slot;
-            if (r.id >= kRecClippedParent) continue;
-            if (px < (int)(r.bbmin & 0xffffu) || px > (int)(r.bbmax & 0xffffu) || py < (int)(r.bbmin >> 16) || py > (int)(r.bbmax >> 16)) continue;
-            Edges e;
-            make_edges(r, e);
-            int64_t E[3];
-            edge_eval(e, px, py, E);
-            if (!edges_inside(e, E)) continue;
-            float z = depth_at(r, E);
-            if (!(z < zbuf)) continue;
-            const float* beta = ri >= a.ws.slots ? a.ws.betas + (size_t)(ri - a.ws.slots) * 9 : nullptr;
-            float B[3];
-            bary_at(r, beta, E, B);
-            V4 w[3];
-            for (int k = 0; k < 3; ++k) {
-                float4 p = a.pos[a.idx[3 * t + k]];
-                w[k] = mat4_mul(a.fc.model_fog, V4{p.x, p.y, p.z, 1.0f});
+    const float zbuf = live ? a.depth[pi] : 0.0f;
+    int nfrag = 0;
+    V3 origin = v3(0.0f, 0.0f, 0.0f);
+    float max_depth = 0.0f;
+    if (live) {
+        for (uint32_t t = 0; t < a.ntris && nfrag < 2; ++t) {
+            Rec slot = load_rec(&a.ws.recs[t]);
+            if (slot.id == kRecInvalid) continue;
+            uint32_t first = t, count = 1;
+            if (slot.id == kRecClippedParent) { first = (uint32_t)slot.X0; count = (uint32_t)slot.Y0; }
+            for (uint32_t s = 0; s < count; ++s) {
+                uint32_t ri = first + s;
+                Rec r = (slot.id == kRecClippedParent) ? load_rec(&a.ws.recs[ri]) : slot;
+                if (r.id >= kRecClippedParent) continue;
+                if (px < (int)(r.bbmin & 0xffffu) || px > (int)(r.bbmax & 0xffffu) || py < (int)(r.bbmin >> 16) || py > (int)(r.bbmax >> 16)) continue;
+                const float* beta = ri >= a.ws.slots ? a.ws.betas + (size_t)(ri - a.ws.slots) * 9 : nullptr;
+                V3 o;
+                float md;
+                if (fog_fragment(a, r, beta, t, px, py, zbuf, o, md)) { origin = o; max_depth = md; ++nfrag; }
             }
-            V3 origin = v3(ip(B, w[0].x, w[1].x, w[2].x), ip(B, w[0].y, w[1].y, w[2].y), ip(B, w[0].z, w[1].z, w[2].z));
-            uint32_t evals = 0;
-            V4 src = fs_fog(a.fc, sm, a.depth, origin, z, px, py, evals);
-            if (COUNT) {
-                atomicAdd(&a.counters[0], 1ull);
-                atomicAdd(&a.counters[1], (unsigned long long)evals);
-            }
-            col = blend_pack(ct, col, src, true);
-            touched = true;
         }
     }
-    if (touched) a.color[pi] = col;
+    if (nfrag >= 2) {
+        // several fog fragments on one pixel: blend them here, one after the other
+        ColorTables ct{a.tables};
+        ShadowMap sm{a.shadow, a.fc.S};
+        uint32_t col = a.color[pi];
+        for (uint32_t t = 0; t < a.ntris; ++t) {
+            Rec slot = load_rec(&a.ws.recs[t]);
+            if (slot.id == kRecInvalid) continue;
+            uint32_t first = t, count = 1;
+            if (slot.id == kRecClippedParent) { first = (uint32_t)slot.X0; count = (uint32_t)slot.Y0; }
+            for (uint32_t s = 0; s < count; ++s) {
+                uint32_t ri = first + s;
+                Rec r = (slot.id == kRecClippedParent) ? load_rec(&a.ws.recs[ri]) : slot;
+                if (r.id >= kRecClippedParent) continue;
+                if (px < (int)(r.bbmin & 0xffffu) || px > (int)(r.bbmax & 0xffffu) || py < (int)(r.bbmin >> 16) || py > (int)(r.bbmax >> 16)) continue;
+                const float* beta = ri >= a.ws.slots ? a.ws.betas + (size_t)(ri - a.ws.slots) * 9 : nullptr;
+                V3 o;
+                float md;
+                if (!fog_fragment(a, r, beta, t, px, py, zbuf, o, md)) continue;
+                uint32_t evals = 0;
+                V4 src = md <= 0.0f ? V4{0.0f, 0.0f, 0.0f, 0.0f} : fog_march_shade(a.fc, sm, o, md, evals);
+                if (COUNT) { atomicAdd(&a.counters[0], 1ull); atomicAdd(&a.counters[1], (unsigned long long)evals); }
+                col = blend_pack(ct, col, src, true);
+            }
+        }
+        a.color[pi] = col;
+    }
+    if (COUNT && nfrag == 1) atomicAdd(&a.counters[0], 1ull);
+    const bool item = nfrag == 1 && max_depth > 0.0f;
+    const unsigned long long mask = __ballot(item);
+    if (mask == 0ull) return;
+    uint32_t base = 0;
+    if (lane == (int)__builtin_ctzll(mask)) base = atomicAdd(a.item_count, (uint32_t)__popcll(mask));
+    base = __shfl(base, (int)__builtin_ctzll(mask));
+    if (item) {
+        uint32_t k = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        a.item_pixel[k] = (uint32_t)pi;
+        a.item_ray[k] = make_float4(origin.x, origin.y, origin.z, max_depth);
+    }
+}
+
+// Fog pass, part 2: one thread per work item runs both marches of fog.wgsl and blends the
+// fog colour over the pixel (SrcAlpha / OneMinusSrcAlpha, state.rs:501).  One wavefront per
+// workgroup, all lanes busy, so the long-running marches spread evenly over the chip.
+template <bool COUNT>
+__global__ __launch_bounds__(64) void k_fog_march(FogArgs a) {
+    const uint32_t k = blockIdx.x * 64u + threadIdx.x;
+    if (k >= *a.item_count) return;
+    const uint32_t pi = a.item_pixel[k];
+    const float4 ray = a.item_ray[k];
+    ColorTables ct{a.tables};
+    ShadowMap sm{a.shadow, a.fc.S};
+    uint32_t evals = 0;
+    V4 src = fog_march_shade(a.fc, sm, v3(ray.x, ray.y, ray.z), ray.w, evals);
+    if (COUNT) atomicAdd(&a.counters[1], (unsigned long long)evals);
+    a.color[pi] = blend_pack(ct, a.color[pi], src, true);
 }
 
 // ------------------------------------------------------------------ bin pack / scatter
