@@ -122,7 +122,7 @@ void dfree(T*& p) {
 }
 
 void free_ws(WsAlloc& w) {
-    dfree(w.ws.recs); dfree(w.ws.betas); dfree(w.counters); dfree(w.ws.bin_offset); dfree(w.ws.bin_items);
+    dfree(w.ws.recs); dfree(w.ws.bb); dfree(w.ws.betas); dfree(w.counters); dfree(w.ws.bin_offset); dfree(w.ws.bin_items);
     w = WsAlloc();
 }
 
@@ -135,6 +135,7 @@ int alloc_ws(WrContext* ctx, WsAlloc& w, uint32_t slots, uint32_t ovf_cap, uint3
     ws.err = err; ws.total_items = total_items;
     size_t nb = (size_t)bins_x * bins_y * layers;
     WR_HIP(hipMalloc(&ws.recs, sizeof(Rec) * (size_t)layers * ((size_t)slots + ovf_cap)));
+    WR_HIP(hipMalloc(&ws.bb, sizeof(uint2) * (size_t)layers * ((size_t)slots + ovf_cap)));
     WR_HIP(hipMalloc(&ws.betas, sizeof(float) * 9 * (size_t)layers * ovf_cap + 64));
     w.counters_bytes = sizeof(uint32_t) * ((size_t)layers + 2 * nb + extra_counters);
     WR_HIP(hipMalloc(&w.counters, w.counters_bytes));
@@ -311,9 +312,8 @@ dim3 grid1(uint32_t n, uint32_t layers = 1) { return dim3((n + 255u) / 256u, lay
 int bin_and_raster(WrContext* ctx, WsAlloc& w, bool shadow, int tr, int tw) {
     RasterWS& ws = w.ws;
     uint32_t nrec = ws.slots + ws.ovf_cap;
-    hipLaunchKernelGGL(k_bin<false>, grid1(nrec, ws.layers), dim3(256), 0, ctx->stream, ws, tr, tw);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, ctx->stream, ws);
-    hipLaunchKernelGGL(k_bin<true>, grid1(nrec, ws.layers), dim3(256), 0, ctx->stream, ws, tr, tw);
+    hipLaunchKernelGGL(k_bin_fill, grid1(nrec, ws.layers), dim3(256), 0, ctx->stream, ws, tr, tw);
     dim3 g((uint32_t)(ws.bins_x * ws.bins_y), (uint32_t)ws.layers, 1);
     if (shadow)
         hipLaunchKernelGGL(k_raster<true>, g, dim3(256), 0, ctx->stream, ws, ctx->S, ctx->S, (uint32_t*)nullptr, ctx->d_shadow, 0, 1);
@@ -327,7 +327,7 @@ int shadow_stage(WrContext* ctx, const FrameConsts& fc) {
     WR_HIP(hipMemsetAsync(ctx->shadow.counters, 0, ctx->shadow.counters_bytes, ctx->stream));
     hipLaunchKernelGGL(k_vs_shadow, grid1(g.nv, 6), dim3(256), 0, ctx->stream, g.pos, g.nv, ctx->d_shadow_clip, fc);
     hipLaunchKernelGGL(k_setup<true>, grid1(g.ntris, 6), dim3(256), 0, ctx->stream, ctx->d_shadow_clip, g.nv, g.idx, g.ntris,
-                       ctx->shadow.ws, ctx->S, ctx->S);
+                       ctx->shadow.ws, ctx->S, ctx->S, 0, 1);
     return bin_and_raster(ctx, ctx->shadow, true, 0, 1);
 }
 
@@ -348,7 +348,7 @@ int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do
     VertexIn vin{g.pos, g.uv, g.nrm, g.tan, g.bit, g.nv};
     hipLaunchKernelGGL(k_vs_geometry, grid1(g.nv), dim3(256), 0, ctx->stream, vin, ctx->vout, fc);
     hipLaunchKernelGGL(k_setup<false>, grid1(g.ntris, 1), dim3(256), 0, ctx->stream, ctx->vout.clip, g.nv, g.idx, g.ntris,
-                       ctx->geom.ws, ctx->W, ctx->H);
+                       ctx->geom.ws, ctx->W, ctx->H, fc.tile_rank, fc.tile_world);
     if (lm.ntris)
         hipLaunchKernelGGL(k_setup_small, grid1(lm.ntris), dim3(256), 0, ctx->stream, lm.pos, lm.idx, lm.ntris, 0,
                            (passes & WR_PASS_LIGHT_DEBUG) ? 1 : 0, g.ntris, ctx->geom.ws, fc);

@@ -1,12 +1,12 @@
 // wr_kernels.h -- gfx950 kernels of the render path.
 //
 // Frame structure (one HIP stream, kernels in this order):
-//   shadow   : k_vs_shadow -> k_setup<true> -> k_bin<count> -> k_scan -> k_bin<fill>
+//   shadow   : k_vs_shadow -> k_setup<true> (set-up + bin counts) -> k_scan -> k_bin_fill
 //              -> k_raster<true>            (6 cube faces as grid.y "layers")
 //   geometry : k_vs_geometry -> k_setup<false> (+ k_setup_small for the light marker)
-//              -> k_bin/k_scan/k_bin -> k_raster<false>   (visibility + depth buffers)
-//   shade    : k_shade                      (deferred pbr.wgsl fragment stage + blending)
-//   fog      : k_setup_small(fog) -> k_fog  (fog.wgsl fragment stage + blending)
+//              -> k_scan -> k_bin_fill -> k_raster<false>   (visibility + depth buffers)
+//   shade    : k_shade -> k_replay          (deferred pbr.wgsl fragment stage; ordered blending)
+//   fog      : k_setup_small(fog) -> k_fog_setup -> k_fog_march   (fog.wgsl fragment stage)
 //
 // The rasteriser is tile-binned: the target is cut into 64x64-pixel bins, every set-up
 // triangle is appended to the list of each bin it can touch, and one 256-thread workgroup
@@ -22,6 +22,7 @@ namespace wr {
 
 struct RasterWS {
     Rec* recs;            // [layers][slots + ovf_cap]
+    uint2* bb;            // [layers][slots + ovf_cap] pixel bounding box of each record, or kBBInvalid
     float* betas;         // [layers][ovf_cap][9] clip weights of records born in the clipper
     uint32_t* ovf_count;  // [layers]
     uint32_t* bin_count;  // [layers * bins]
@@ -99,10 +100,85 @@ __device__ inline Rec load_rec(const Rec* src) {
     return r;
 }
 
+constexpr uint32_t kBBInvalid = 0xFFFFFFFFu;
+
+// Adds 1 to counters[key] for every lane with `active`, with one atomic per distinct key in
+// the wavefront (ballot + leader), and returns to each such lane the value its own
+// atomicAdd(…, 1) would have returned in lane order.  Neighbouring triangles of a mesh land
+// in the same bin, so this removes almost all same-address atomic traffic.  Every lane that
+// has not exited the kernel must call it.
+__device__ inline uint32_t wave_agg_inc(uint32_t* counters, bool active, uint32_t key) {
+    const int lane = (int)(threadIdx.x & 63u);
+    uint32_t pos = 0;
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+        const int leader = (int)__builtin_ctzll(todo);
+        const uint32_t lkey = (uint32_t)__shfl((int)key, leader);
+        const bool mine = active && key == lkey;
+        const unsigned long long m = __ballot(mine);
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&counters[lkey], (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, leader);
+        if (mine) pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        todo &= ~m;
+    }
+    return pos;
+}
+
+__device__ inline bool bin_owned(int b, int tile_rank, int tile_world) {
+    return tile_world <= 1 || (b % tile_world) == tile_rank;
+}
+
+// Bins of a record whose bounding box spans several bins: every bin of the box that the
+// triangle's edges do not rule out.  FILL = false counts, FILL = true appends the record
+// index; both make the same decisions.
+template <bool FILL>
+__device__ inline void bin_record_multi(const RasterWS& ws, uint32_t layer, uint32_t rec_index, const Rec& r,
+                                        int tile_rank, int tile_world) {
+    int pxmin = (int)(r.bbmin & 0xffffu), pymin = (int)(r.bbmin >> 16);
+    int pxmax = (int)(r.bbmax & 0xffffu), pymax = (int)(r.bbmax >> 16);
+    Edges e;
+    make_edges(r, e);
+    const uint32_t nb = (uint32_t)(ws.bins_x * ws.bins_y);
+    for (int by = pymin / kBin; by <= pymax / kBin; ++by)
+        for (int bx = pxmin / kBin; bx <= pxmax / kBin; ++bx) {
+            int b = by * ws.bins_x + bx;
+            if (!bin_owned(b, tile_rank, tile_world)) continue;
+            int x0 = imax(bx * kBin, pxmin), x1 = imin(bx * kBin + kBin - 1, pxmax);
+            int y0 = imax(by * kBin, pymin), y1 = imin(by * kBin + kBin - 1, pymax);
+            if (box_rejected(e, x0, y0, x1, y1)) continue;
+            uint32_t gb = layer * nb + (uint32_t)b;
+            if (!FILL) {
+                atomicAdd(&ws.bin_count[gb], 1u);
+            } else {
+                uint32_t o = ws.bin_offset[gb] + atomicAdd(&ws.bin_cursor[gb], 1u);
+                if (o < ws.items_cap) ws.bin_items[o] = rec_index;
+            }
+        }
+}
+
+__device__ inline bool bb_single_bin(uint32_t bbmin, uint32_t bbmax, int bins_x, int& b) {
+    int bx0 = (int)(bbmin & 0xffffu) / kBin, by0 = (int)(bbmin >> 16) / kBin;
+    int bx1 = (int)(bbmax & 0xffffu) / kBin, by1 = (int)(bbmax >> 16) / kBin;
+    b = by0 * bins_x + bx0;
+    return bx0 == bx1 && by0 == by1;
+}
+
+struct SetupTarget {
+    Rec* recs;          // this layer's records
+    uint2* bb;          // this layer's bounding boxes (bbmin = kBBInvalid: nothing to bin)
+    float* betas;
+    uint32_t* ovf_count;
+    uint32_t layer;
+    int W, H, tile_rank, tile_world;
+    bool count;         // false: no binning for this target (the fog volume is not binned)
+};
+
+// Clip path: the fan triangles go to the overflow region of the record array, the parent
+// slot keeps where they are.  Rare, so its bins are counted without aggregation.
 template <bool SHADOW>
-__device__ __attribute__((noinline)) void emit_clipped(const V4* c, uint32_t tri, Rec* recs, uint32_t slot,
-                                                       float* betas, uint32_t* ovf_count, uint32_t slots,
-                                                       uint32_t ovf_cap, uint32_t* err, int W, int H) {
+__device__ __attribute__((noinline)) void emit_clipped(const V4* c, uint32_t tri, uint32_t slot, const RasterWS& ws,
+                                                       const SetupTarget& tg) {
     ClipVert poly[10];
     for (int k = 0; k < 3; ++k) {
         poly[k].x = c[k].x; poly[k].y = c[k].y; poly[k].z = c[k].z; poly[k].w = c[k].w;
@@ -113,62 +189,110 @@ __device__ __attribute__((noinline)) void emit_clipped(const V4* c, uint32_t tri
     parent.id = kRecInvalid;
     if (n >= 3) {
         uint32_t nf = (uint32_t)(n - 2);
-        uint32_t base = atomicAdd(ovf_count, nf);
-        if (base + nf > ovf_cap) {
-            atomicOr(err, kErrClipOverflow);
+        uint32_t base = atomicAdd(tg.ovf_count, nf);
+        if (base + nf > ws.ovf_cap) {
+            atomicOr(ws.err, kErrClipOverflow);
         } else {
             for (uint32_t i = 0; i < nf; ++i) {
                 ClipVert cv[3] = {poly[0], poly[i + 1], poly[i + 2]};
                 Rec r;
                 float beta[9];
-                if (!setup_sub(cv, W, H, SHADOW, (tri << 3) | i, r, beta)) r.id = kRecInvalid;
-                store_rec(&recs[slots + base + i], r);
-                float* bd = betas + (size_t)(base + i) * 9;
-                for (int k = 0; k < 9; ++k) bd[k] = beta[k];
+                uint32_t ri = ws.slots + base + i;
+                if (setup_sub(cv, tg.W, tg.H, SHADOW, (tri << 3) | i, r, beta)) {
+                    store_rec(&tg.recs[ri], r);
+                    tg.bb[ri] = make_uint2(r.bbmin, r.bbmax);
+                    float* bd = tg.betas + (size_t)(base + i) * 9;
+                    for (int k = 0; k < 9; ++k) bd[k] = beta[k];
+                    if (tg.count) {
+                        // same rule as k_bin_fill: a box inside one bin is binned without the edge test
+                        int b = 0;
+                        if (bb_single_bin(r.bbmin, r.bbmax, ws.bins_x, b)) {
+                            if (bin_owned(b, tg.tile_rank, tg.tile_world))
+                                atomicAdd(&ws.bin_count[tg.layer * (uint32_t)(ws.bins_x * ws.bins_y) + (uint32_t)b], 1u);
+                        } else {
+                            bin_record_multi<false>(ws, tg.layer, ri, r, tg.tile_rank, tg.tile_world);
+                        }
+                    }
+                } else {
+                    r.id = kRecInvalid;
+                    store_rec(&tg.recs[ri], r);
+                    tg.bb[ri] = make_uint2(kBBInvalid, 0u);
+                }
             }
             parent.id = kRecClippedParent;
-            parent.X0 = (int32_t)(slots + base);
+            parent.X0 = (int32_t)(ws.slots + base);
             parent.Y0 = (int32_t)nf;
         }
     }
-    store_rec(&recs[slot], parent);
+    store_rec(&tg.recs[slot], parent);
+    tg.bb[slot] = make_uint2(kBBInvalid, 0u);
 }
 
+// Sets up one triangle, stores its record (only if something can be covered), its bounding
+// box, and counts it into the bins it touches.  `have` is false for lanes past the end of
+// the triangle list; they still take part in the wave-aggregated counting.
 template <bool SHADOW>
-__device__ inline void emit_triangle(const V4* c, uint32_t tri, Rec* recs, uint32_t slot, float* betas,
-                                     uint32_t* ovf_count, uint32_t slots, uint32_t ovf_cap, uint32_t* err,
-                                     int W, int H) {
-    int cls = classify_triangle(c);
-    if (cls == 2) {
-        emit_clipped<SHADOW>(c, tri, recs, slot, betas, ovf_count, slots, ovf_cap, err, W, H);
-        return;
-    }
+__device__ inline void emit_triangle(bool have, const V4* c, uint32_t tri, uint32_t slot, const RasterWS& ws,
+                                     const SetupTarget& tg) {
     Rec r;
     r.id = kRecInvalid;
-    if (cls == 1) {
-        ClipVert cv[3];
-        for (int k = 0; k < 3; ++k) { cv[k].x = c[k].x; cv[k].y = c[k].y; cv[k].z = c[k].z; cv[k].w = c[k].w; cv[k].b0 = cv[k].b1 = cv[k].b2 = 0.0f; }
-        if (!setup_sub(cv, W, H, SHADOW, tri << 3, r, nullptr)) r.id = kRecInvalid;
+    bool valid = false;
+    if (have) {
+        int cls = classify_triangle(c);
+        if (cls == 2) {
+            emit_clipped<SHADOW>(c, tri, slot, ws, tg);
+        } else {
+            if (cls == 1) {
+                ClipVert cv[3];
+                for (int k = 0; k < 3; ++k) { cv[k].x = c[k].x; cv[k].y = c[k].y; cv[k].z = c[k].z; cv[k].w = c[k].w; cv[k].b0 = cv[k].b1 = cv[k].b2 = 0.0f; }
+                valid = setup_sub(cv, tg.W, tg.H, SHADOW, tri << 3, r, nullptr);
+            }
+            if (valid) {
+                store_rec(&tg.recs[slot], r);
+                tg.bb[slot] = make_uint2(r.bbmin, r.bbmax);
+            } else {
+                tg.recs[slot].id = kRecInvalid;
+                tg.bb[slot] = make_uint2(kBBInvalid, 0u);
+            }
+        }
     }
-    store_rec(&recs[slot], r);
+    if (!tg.count) return;
+    int b = 0;
+    const bool single = valid && bb_single_bin(r.bbmin, r.bbmax, ws.bins_x, b);
+    const uint32_t gb = tg.layer * (uint32_t)(ws.bins_x * ws.bins_y) + (uint32_t)b;
+    wave_agg_inc(ws.bin_count, single && bin_owned(b, tg.tile_rank, tg.tile_world), gb);
+    if (valid && !single) bin_record_multi<false>(ws, tg.layer, slot, r, tg.tile_rank, tg.tile_world);
+}
+
+__device__ inline SetupTarget setup_target(const RasterWS& ws, uint32_t layer, int W, int H, int tile_rank, int tile_world) {
+    SetupTarget tg;
+    size_t stride = (size_t)ws.slots + ws.ovf_cap;
+    tg.recs = ws.recs + layer * stride;
+    tg.bb = ws.bb + layer * stride;
+    tg.betas = ws.betas + (size_t)layer * ws.ovf_cap * 9;
+    tg.ovf_count = ws.ovf_count + layer;
+    tg.layer = layer;
+    tg.W = W; tg.H = H; tg.tile_rank = tile_rank; tg.tile_world = tile_world;
+    tg.count = true;
+    return tg;
 }
 
 // One thread per triangle of the geometry model; grid.y = layer (cube face for shadows).
 template <bool SHADOW>
 __global__ __launch_bounds__(256) void k_setup(const float4* clip, uint32_t nv, const uint32_t* idx, uint32_t ntris,
-                                               RasterWS ws, int W, int H) {
+                                               RasterWS ws, int W, int H, int tile_rank, int tile_world) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= ntris) return;
+    const bool have = t < ntris;
     uint32_t layer = blockIdx.y;
     const float4* cl = clip + (size_t)layer * nv;
     V4 c[3];
-    for (int k = 0; k < 3; ++k) {
-        float4 v = cl[idx[3 * t + k]];
-        c[k] = V4{v.x, v.y, v.z, v.w};
-    }
-    Rec* recs = ws.recs + (size_t)layer * (ws.slots + ws.ovf_cap);
-    float* betas = ws.betas + (size_t)layer * ws.ovf_cap * 9;
-    emit_triangle<SHADOW>(c, t, recs, t, betas, ws.ovf_count + layer, ws.slots, ws.ovf_cap, ws.err, W, H);
+    if (have)
+        for (int k = 0; k < 3; ++k) {
+            float4 v = cl[idx[3 * t + k]];
+            c[k] = V4{v.x, v.y, v.z, v.w};
+        }
+    SetupTarget tg = setup_target(ws, layer, W, H, tile_rank, tile_world);
+    emit_triangle<SHADOW>(have, c, t, t, ws, tg);
 }
 
 // The two 12-triangle helper models.  mode 0: light marker (light_debug.wgsl:12-21), its
@@ -177,59 +301,52 @@ __global__ __launch_bounds__(256) void k_setup(const float4* clip, uint32_t nv, 
 __global__ void k_setup_small(const float4* pos, const uint32_t* idx, uint32_t ntris, int mode, int enabled,
                               uint32_t slot_base, RasterWS ws, FrameConsts fc) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= ntris) return;
-    if (!enabled) {
-        Rec r;
-        r.id = kRecInvalid;
-        store_rec(&ws.recs[slot_base + t], r);
-        return;
+    const bool have = t < ntris && enabled;
+    if (t < ntris && !enabled) {
+        ws.recs[slot_base + t].id = kRecInvalid;
+        ws.bb[slot_base + t] = make_uint2(kBBInvalid, 0u);
     }
     V4 c[3];
-    for (int k = 0; k < 3; ++k) {
-        float4 p = pos[idx[3 * t + k]];
-        V4 wp;
-        if (mode == 0) wp = V4{p.x * 10.0f + fc.light_pos[0], p.y * 10.0f + fc.light_pos[1], p.z * 10.0f + fc.light_pos[2], 1.0f};
-        else wp = mat4_mul(fc.model_fog, V4{p.x, p.y, p.z, 1.0f});
-        c[k] = mat4_mul(fc.pv, wp);
-    }
-    emit_triangle<false>(c, slot_base + t, ws.recs, slot_base + t, ws.betas, ws.ovf_count, ws.slots, ws.ovf_cap,
-                         ws.err, fc.W, fc.H);
+    if (have)
+        for (int k = 0; k < 3; ++k) {
+            float4 p = pos[idx[3 * t + k]];
+            V4 wp;
+            if (mode == 0) wp = V4{p.x * 10.0f + fc.light_pos[0], p.y * 10.0f + fc.light_pos[1], p.z * 10.0f + fc.light_pos[2], 1.0f};
+            else wp = mat4_mul(fc.model_fog, V4{p.x, p.y, p.z, 1.0f});
+            c[k] = mat4_mul(fc.pv, wp);
+        }
+    SetupTarget tg = setup_target(ws, 0, fc.W, fc.H, fc.tile_rank, fc.tile_world);
+    tg.count = mode == 0;
+    emit_triangle<false>(have, c, slot_base + t, slot_base + t, ws, tg);
 }
 
 // ------------------------------------------------------------------ binning
-// Pass 1 (FILL = false) counts, pass 2 (FILL = true) writes record indices; both walk the
-// same bins with the same reject test, so counts and fills agree.
-template <bool FILL>
-__global__ __launch_bounds__(256) void k_bin(RasterWS ws, int tile_rank, int tile_world) {
+// Bin counts are accumulated by the set-up kernels; after k_scan turned them into offsets
+// this kernel appends every record index to the list of each bin it touches.  One thread
+// per record slot, reading only the 8-byte bounding boxes; records inside one bin (almost
+// all) are appended with wave-aggregated atomics.
+__global__ __launch_bounds__(256) void k_bin_fill(RasterWS ws, int tile_rank, int tile_world) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t layer = blockIdx.y;
     uint32_t ovf = ws.ovf_count[layer];
     if (ovf > ws.ovf_cap) ovf = ws.ovf_cap;
-    if (i >= ws.slots + ovf) return;
-    const Rec* recs = ws.recs + (size_t)layer * (ws.slots + ws.ovf_cap);
-    Rec r = load_rec(&recs[i]);
-    if (r.id >= kRecClippedParent) return;
-    int pxmin = (int)(r.bbmin & 0xffffu), pymin = (int)(r.bbmin >> 16);
-    int pxmax = (int)(r.bbmax & 0xffffu), pymax = (int)(r.bbmax >> 16);
-    Edges e;
-    make_edges(r, e);
-    int nb = ws.bins_x * ws.bins_y;
-    for (int by = pymin / kBin; by <= pymax / kBin; ++by)
-        for (int bx = pxmin / kBin; bx <= pxmax / kBin; ++bx) {
-            int b = by * ws.bins_x + bx;
-            if (tile_world > 1 && (b % tile_world) != tile_rank) continue;
-            int x0 = imax(bx * kBin, pxmin), x1 = imin(bx * kBin + kBin - 1, pxmax);
-            int y0 = imax(by * kBin, pymin), y1 = imin(by * kBin + kBin - 1, pymax);
-            if (box_rejected(e, x0, y0, x1, y1)) continue;
-            uint32_t gb = layer * (uint32_t)nb + (uint32_t)b;
-            if (!FILL) {
-                atomicAdd(&ws.bin_count[gb], 1u);
-            } else {
-                uint32_t pos = atomicAdd(&ws.bin_cursor[gb], 1u);
-                uint32_t o = ws.bin_offset[gb] + pos;
-                if (o < ws.items_cap) ws.bin_items[o] = i;
-            }
-        }
+    const size_t stride = (size_t)ws.slots + ws.ovf_cap;
+    uint2 bb = make_uint2(kBBInvalid, 0u);
+    if (i < ws.slots + ovf) bb = ws.bb[layer * stride + i];
+    const bool valid = bb.x != kBBInvalid;
+    int b = 0;
+    const bool single = valid && bb_single_bin(bb.x, bb.y, ws.bins_x, b);
+    const uint32_t gb = layer * (uint32_t)(ws.bins_x * ws.bins_y) + (uint32_t)b;
+    const bool go = single && bin_owned(b, tile_rank, tile_world);
+    uint32_t pos = wave_agg_inc(ws.bin_cursor, go, gb);
+    if (go) {
+        uint32_t o = ws.bin_offset[gb] + pos;
+        if (o < ws.items_cap) ws.bin_items[o] = i;
+    }
+    if (valid && !single) {
+        Rec r = load_rec(&ws.recs[layer * stride + i]);
+        bin_record_multi<true>(ws, layer, i, r, tile_rank, tile_world);
+    }
 }
 
 // Exclusive prefix sum of the bin counts (one 1024-thread workgroup; n is a few thousand).
@@ -261,55 +378,88 @@ __global__ __launch_bounds__(1024) void k_scan(RasterWS ws) {
 }
 
 // ------------------------------------------------------------------ rasteriser
-// One workgroup per (bin, layer).  SHADOW: depth-only, LessEqual with bias -> plain min of
-// the biased depth (pass.rs:118-126).  Otherwise depth test Less with depth write
-// (state.rs:467,482): the smallest (depth, id) key wins, ties go to the earlier draw.
+// One workgroup per (bin, layer) resolves the bin in an LDS tile and writes it out once.
+// SHADOW: depth-only, LessEqual with bias -> plain min of the biased depth
+// (pass.rs:118-126).  Otherwise depth test Less with depth write (state.rs:467,482): the
+// smallest (depth, id) key wins, ties go to the earlier draw.
+//
+// The bin's triangle list is consumed 256 records at a time, one record per thread, all
+// loads in flight together.  A triangle whose box inside the bin is at most 4x4 pixels is
+// rasterised by the thread that fetched it; larger ones are parked in LDS and then taken
+// one per wavefront, 64 lanes testing one 8x8 pixel block per step.
+template <bool SHADOW>
+__device__ inline void raster_pixel(const Rec& r, const Edges& e, int px, int py, int ox, int oy,
+                                    unsigned long long* tile, uint32_t* tile32) {
+    int64_t E[3];
+    edge_eval(e, px, py, E);
+    if (!edges_inside(e, E)) return;
+    float z = depth_at(r, E);
+    int li = (py - oy) * kBin + (px - ox);
+    if (SHADOW) {
+        float zb = fminf(fmaxf(z + r.iw0, 0.0f), 1.0f);
+        atomicMin(&tile32[li], f2u(zb));
+    } else {
+        if (z < 1.0f) atomicMin(&tile[li], ((unsigned long long)f2u(z) << 32) | (unsigned long long)r.id);
+    }
+}
+
 template <bool SHADOW>
 __global__ __launch_bounds__(256) void k_raster(RasterWS ws, int W, int H, uint32_t* vis, float* depth,
                                                 int tile_rank, int tile_world) {
     __shared__ unsigned long long tile[SHADOW ? 1 : kBin * kBin];
     __shared__ uint32_t tile32[SHADOW ? kBin * kBin : 1];
+    __shared__ Rec bigq[256];
+    __shared__ uint32_t s_nbig;
     const int b = blockIdx.x, layer = blockIdx.y;
-    if (tile_world > 1 && (b % tile_world) != tile_rank) return;
+    if (!bin_owned(b, tile_rank, tile_world)) return;
     const int bx = b % ws.bins_x, by = b / ws.bins_x;
     const int ox = bx * kBin, oy = by * kBin;
     for (int i = threadIdx.x; i < kBin * kBin; i += 256) {
         if (SHADOW) tile32[i] = 0x3F800000u;
         else tile[i] = 0x3F800000FFFFFFFFull;
     }
-    __syncthreads();
     const uint32_t gb = (uint32_t)layer * (uint32_t)(ws.bins_x * ws.bins_y) + (uint32_t)b;
     const uint32_t n = ws.bin_count[gb], off = ws.bin_offset[gb];
-    const Rec* recs = ws.recs + (size_t)layer * (ws.slots + ws.ovf_cap);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const Rec* recs = ws.recs + (size_t)layer * ((size_t)ws.slots + ws.ovf_cap);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lx = lane & 7, ly = lane >> 3;
-    for (uint32_t i = wave; i < n; i += 4) {
-        if (off + i >= ws.items_cap) break;
-        uint32_t ri = __builtin_amdgcn_readfirstlane(ws.bin_items[off + i]);
-        Rec r = load_rec(&recs[ri]);
-        Edges e;
-        make_edges(r, e);
-        int x0 = imax((int)(r.bbmin & 0xffffu), ox), x1 = imin((int)(r.bbmax & 0xffffu), ox + kBin - 1);
-        int y0 = imax((int)(r.bbmin >> 16), oy), y1 = imin((int)(r.bbmax >> 16), oy + kBin - 1);
-        for (int qy = y0 >> 3; qy <= (y1 >> 3); ++qy)
-            for (int qx = x0 >> 3; qx <= (x1 >> 3); ++qx) {
-                int bx0 = imax(qx * 8, x0), bx1 = imin(qx * 8 + 7, x1);
-                int by0 = imax(qy * 8, y0), by1 = imin(qy * 8 + 7, y1);
-                if (box_rejected(e, bx0, by0, bx1, by1)) continue;
-                int px = qx * 8 + lx, py = qy * 8 + ly;
-                if (px < x0 || px > x1 || py < y0 || py > y1) continue;
-                int64_t E[3];
-                edge_eval(e, px, py, E);
-                if (!edges_inside(e, E)) continue;
-                float z = depth_at(r, E);
-                int li = (py - oy) * kBin + (px - ox);
-                if (SHADOW) {
-                    float zb = fminf(fmaxf(z + r.iw0, 0.0f), 1.0f);
-                    atomicMin(&tile32[li], f2u(zb));
-                } else {
-                    if (z < 1.0f) atomicMin(&tile[li], ((unsigned long long)f2u(z) << 32) | (unsigned long long)r.id);
-                }
+    for (uint32_t c0 = 0; c0 < n; c0 += 256) {
+        if (tid == 0) s_nbig = 0;
+        __syncthreads();  // also orders the tile initialisation before the first atomics
+        if (c0 + tid < n && off + c0 + tid < ws.items_cap) {
+            Rec r = load_rec(&recs[ws.bin_items[off + c0 + tid]]);
+            int x0 = imax((int)(r.bbmin & 0xffffu), ox), x1 = imin((int)(r.bbmax & 0xffffu), ox + kBin - 1);
+            int y0 = imax((int)(r.bbmin >> 16), oy), y1 = imin((int)(r.bbmax >> 16), oy + kBin - 1);
+            if (x1 - x0 < 4 && y1 - y0 < 4) {
+                Edges e;
+                make_edges(r, e);
+                for (int py = y0; py <= y1; ++py)
+                    for (int px = x0; px <= x1; ++px) raster_pixel<SHADOW>(r, e, px, py, ox, oy, tile, tile32);
+            } else {
+                bigq[atomicAdd(&s_nbig, 1u)] = r;
             }
+        }
+        __syncthreads();
+        const uint32_t nbig = s_nbig;
+        for (uint32_t q = wave; q < nbig; q += 4) {
+            Rec r = bigq[q];
+            Edges e;
+            make_edges(r, e);
+            int x0 = __builtin_amdgcn_readfirstlane(imax((int)(r.bbmin & 0xffffu), ox));
+            int x1 = __builtin_amdgcn_readfirstlane(imin((int)(r.bbmax & 0xffffu), ox + kBin - 1));
+            int y0 = __builtin_amdgcn_readfirstlane(imax((int)(r.bbmin >> 16), oy));
+            int y1 = __builtin_amdgcn_readfirstlane(imin((int)(r.bbmax >> 16), oy + kBin - 1));
+            for (int qy = y0 >> 3; qy <= (y1 >> 3); ++qy)
+                for (int qx = x0 >> 3; qx <= (x1 >> 3); ++qx) {
+                    int bx0 = imax(qx * 8, x0), bx1 = imin(qx * 8 + 7, x1);
+                    int by0 = imax(qy * 8, y0), by1 = imin(qy * 8 + 7, y1);
+                    if (__builtin_amdgcn_readfirstlane((int)box_rejected(e, bx0, by0, bx1, by1))) continue;
+                    int px = qx * 8 + lx, py = qy * 8 + ly;
+                    if (px < x0 || px > x1 || py < y0 || py > y1) continue;
+                    raster_pixel<SHADOW>(r, e, px, py, ox, oy, tile, tile32);
+                }
+        }
+        __syncthreads();
     }
     __syncthreads();
     for (int i = threadIdx.x; i < kBin * kBin; i += 256) {
