@@ -384,9 +384,10 @@ __global__ __launch_bounds__(1024) void k_scan(RasterWS ws) {
 // smallest (depth, id) key wins, ties go to the earlier draw.
 //
 // The bin's triangle list is consumed 256 records at a time, one record per thread, all
-// loads in flight together.  A triangle whose box inside the bin is at most 4x4 pixels is
-// rasterised by the thread that fetched it; larger ones are parked in LDS and then taken
-// one per wavefront, 64 lanes testing one 8x8 pixel block per step.
+// loads in flight together.  A triangle of at most 16x16 pixels with at most 64 pixels of
+// its box inside the bin is rasterised by the thread that fetched it (64 triangles per
+// wavefront in flight); larger ones are parked in LDS and then taken one per wavefront,
+// 64 lanes testing one 8x8 pixel block per step.
 template <bool SHADOW>
 __device__ inline void raster_pixel(const Rec& r, const Edges& e, int px, int py, int ox, int oy,
                                     unsigned long long* tile, uint32_t* tile32) {
@@ -430,11 +431,38 @@ __global__ __launch_bounds__(256) void k_raster(RasterWS ws, int W, int H, uint3
             Rec r = load_rec(&recs[ws.bin_items[off + c0 + tid]]);
             int x0 = imax((int)(r.bbmin & 0xffffu), ox), x1 = imin((int)(r.bbmax & 0xffffu), ox + kBin - 1);
             int y0 = imax((int)(r.bbmin >> 16), oy), y1 = imin((int)(r.bbmax >> 16), oy + kBin - 1);
-            if (x1 - x0 < 4 && y1 - y0 < 4) {
+            const int fw = imax(r.X0, imax(r.X1, r.X2)) - imin(r.X0, imin(r.X1, r.X2));
+            const int fh = imax(r.Y0, imax(r.Y1, r.Y2)) - imin(r.Y0, imin(r.Y1, r.Y2));
+            if (fw <= 16 * 256 && fh <= 16 * 256 && (x1 - x0 + 1) * (y1 - y0 + 1) <= 64) {
+                // The triangle's vertices span at most 16x16 pixels, so every edge function
+                // stays below 2^31 over its box and can be stepped in 32-bit integers; the
+                // values are the same integers the 64-bit evaluation gives.
                 Edges e;
                 make_edges(r, e);
-                for (int py = y0; py <= y1; ++py)
-                    for (int px = x0; px <= x1; ++px) raster_pixel<SHADOW>(r, e, px, py, ox, oy, tile, tile32);
+                int64_t E[3];
+                edge_eval(e, x0, y0, E);
+                const int32_t dx0 = e.A[0] * 256, dx1 = e.A[1] * 256, dx2 = e.A[2] * 256;
+                const int32_t dy0 = e.B[0] * 256, dy1 = e.B[1] * 256, dy2 = e.B[2] * 256;
+                int32_t r0 = (int32_t)E[0] + e.tlb[0], r1 = (int32_t)E[1] + e.tlb[1], r2 = (int32_t)E[2] + e.tlb[2];
+                for (int py = y0; py <= y1; ++py) {
+                    int32_t b0 = r0, b1 = r1, b2 = r2;
+                    for (int px = x0; px <= x1; ++px) {
+                        if ((b0 | b1 | b2) >= 0) {
+                            float l1 = (float)(b1 - e.tlb[1]) * r.inv2A, l2 = (float)(b2 - e.tlb[2]) * r.inv2A;
+                            float z = (r.z0 + l1 * r.dz1) + l2 * r.dz2;
+                            z = fminf(fmaxf(z, 0.0f), 1.0f);
+                            int li = (py - oy) * kBin + (px - ox);
+                            if (SHADOW) {
+                                float zb = fminf(fmaxf(z + r.iw0, 0.0f), 1.0f);
+                                atomicMin(&tile32[li], f2u(zb));
+                            } else {
+                                if (z < 1.0f) atomicMin(&tile[li], ((unsigned long long)f2u(z) << 32) | (unsigned long long)r.id);
+                            }
+                        }
+                        b0 += dx0; b1 += dx1; b2 += dx2;
+                    }
+                    r0 += dy0; r1 += dy1; r2 += dy2;
+                }
             } else {
                 bigq[atomicAdd(&s_nbig, 1u)] = r;
             }
