@@ -140,15 +140,15 @@ def main():
 
     gather_buf = packed = None
     if args.workload == "tiles4k" and world > 1:
-        nb = ((W + 63) // 64) * ((H + 63) // 64)
-        per = (nb + world - 1) // world
+        from wgpu_renderer_amd import sharding
+        per = sharding.bins_per_rank(W, H, world)
         packed = torch.zeros(per * 64 * 64, dtype=torch.int32, device="cuda")
         gather_buf = torch.zeros(world * per * 64 * 64, dtype=torch.int32, device="cuda")
 
     poses = None
     if args.workload == "posebatch":
-        per_rank = args.poses // world
-        mine = range(rank * per_rank, (rank + 1) * per_rank)
+        from wgpu_renderer_amd import sharding
+        mine = sharding.pose_shard(args.poses, rank, world)
 
         def pose_camera(k):
             pos, pitch, yaw = scene.flythrough_pose(k, args.poses)

@@ -1,0 +1,94 @@
+"""Multi-rank host logic on CPU: pose sharding, screen-bin ownership, and the packed-bin
+all_gather with world_size 2 and 3 over the gloo backend."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import wgpu_renderer_amd  # noqa: F401
+from wgpu_renderer_amd import sharding
+
+
+def test_pose_shards_partition_the_batch():
+    for n, world in ((512, 8), (512, 3), (5, 8), (0, 2)):
+        seen = []
+        for r in range(world):
+            seen += list(sharding.pose_shard(n, r, world))
+        assert seen == list(range(n))
+        sizes = [len(sharding.pose_shard(n, r, world)) for r in range(world)]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_bins_are_dealt_round_robin_and_cover_the_frame():
+    w, h = 3840, 2160
+    bx, by = sharding.bin_grid(w, h)
+    assert (bx, by) == (60, 34)
+    for world in (1, 2, 4, 8, 7):
+        allb = sorted(b for r in range(world) for b in sharding.owned_bins(w, h, r, world))
+        assert allb == list(range(bx * by))
+        assert all(len(sharding.owned_bins(w, h, r, world)) <= sharding.bins_per_rank(w, h, world) for r in range(world))
+
+
+@pytest.mark.parametrize("w,h,world", [(1920, 1080, 3), (333, 207, 2), (64, 64, 4)])
+def test_pack_scatter_round_trip_single_process(w, h, world):
+    rng = np.random.default_rng(0)
+    frame = rng.integers(0, 2 ** 32, (h, w), dtype=np.uint32)
+    out = np.zeros_like(frame)
+    for r in range(world):
+        sharding.scatter_bins_host(out, sharding.pack_bins_host(frame, r, world), r, world)
+    assert np.array_equal(out, frame)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, w, h, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # every rank "renders" the same deterministic frame but keeps only its own bins
+        rng = np.random.default_rng(42)
+        truth = rng.integers(0, 2 ** 31, (h, w), dtype=np.int64).astype(np.uint32)
+        mine = np.zeros_like(truth)
+        sharding.scatter_bins_host(mine, sharding.pack_bins_host(truth, rank, world), rank, world)  # foreign bins stay 0
+        packed = torch.from_numpy(sharding.pack_bins_host(mine, rank, world).astype(np.int32))
+        gathered = sharding.gather_packed(packed, world).numpy().astype(np.uint32)
+        frame = np.zeros_like(truth)
+        for r in range(world):
+            sharding.scatter_bins_host(frame, gathered[r], r, world)
+        ok = bool(np.array_equal(frame, truth))
+        # frame-parallel: disjoint pose shards, slowest rank's time is what gets reported
+        poses = list(sharding.pose_shard(17, rank, world))
+        counts = [None] * world
+        dist.all_gather_object(counts, poses)
+        ok &= sorted(p for c in counts for p in c) == list(range(17))
+        slow = sharding.max_over_ranks(1.0 + rank)
+        ok &= slow == float(world)
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_bin_gather_and_pose_split(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 200, 150, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(r, True) for r in range(world)]

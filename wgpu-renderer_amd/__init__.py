@@ -5,5 +5,5 @@ HIP kernels behind the C ABI of include/wr_abi.h; this package is the Python hos
 `abi` binds the library with ctypes, `scene` builds the benchmark inputs, `gltf_loader`
 imports GLB files the way the reference does, `sharding` splits frames across ranks.
 """
-from . import abi, scene  # noqa: F401
+from . import abi, scene, sharding  # noqa: F401
 from .abi import Renderer, WrError  # noqa: F401
