@@ -316,9 +316,9 @@ int bin_and_raster(WrContext* ctx, WsAlloc& w, bool shadow, int tr, int tw) {
     hipLaunchKernelGGL(k_bin_fill, grid1(nrec, ws.layers), dim3(256), 0, ctx->stream, ws, tr, tw);
     dim3 g((uint32_t)(ws.bins_x * ws.bins_y), (uint32_t)ws.layers, 1);
     if (shadow)
-        hipLaunchKernelGGL(k_raster<true>, g, dim3(256), 0, ctx->stream, ws, ctx->S, ctx->S, (uint32_t*)nullptr, ctx->d_shadow, 0, 1);
+        hipLaunchKernelGGL((k_raster<true, 256>), g, dim3(256), 0, ctx->stream, ws, ctx->S, ctx->S, (uint32_t*)nullptr, ctx->d_shadow, 0, 1);
     else
-        hipLaunchKernelGGL(k_raster<false>, g, dim3(256), 0, ctx->stream, ws, ctx->W, ctx->H, ctx->d_vis, ctx->d_depth, tr, tw);
+        hipLaunchKernelGGL((k_raster<false, 1024>), g, dim3(1024), 0, ctx->stream, ws, ctx->W, ctx->H, ctx->d_vis, ctx->d_depth, tr, tw);
     return WR_OK;
 }
 

@@ -79,14 +79,19 @@ inline void mat4_mul_mat4(const float* a, const float* b, float* out) {  // out 
 // Software sine used by the fog noise hash (noise.wgsl:4).  Single-precision Cephes
 // scheme: octant j from x*4/pi, three-constant reduction, one of two cubic-in-z
 // polynomials; the reduction and Horner steps are fused multiply-adds.  |x| >= 2^30 -> 0.
-WR_HD float wr_sin(float x) {
+// GUARD = false is for callers that have already bounded |x| below 2^30; for such x both
+// forms return the same bits.
+template <bool GUARD>
+WR_HD float wr_sin_t(float x) {
     float ax = fabsf(x);
-    // Branch-free range guard: an out-of-range (or NaN) argument is replaced by +0 on entry,
-    // for which the arithmetic below yields +0, so the eight hashes of one lattice cell stay
-    // in one basic block and the scheduler can interleave their dependent chains.
-    bool in_range = ax < 1073741824.0f;
-    ax = in_range ? ax : 0.0f;
-    uint32_t sign = in_range ? (f2u(x) & 0x80000000u) : 0u;
+    uint32_t sign = f2u(x) & 0x80000000u;
+    if (GUARD) {
+        // Branch-free: an out-of-range (or NaN) argument is replaced by +0 on entry, for
+        // which the arithmetic below yields +0.
+        bool in_range = ax < 1073741824.0f;
+        ax = in_range ? ax : 0.0f;
+        sign = in_range ? sign : 0u;
+    }
     float y = ax * 1.27323954473516f;
     int j = (int)y;
     j = (j + 1) & ~1;
@@ -111,6 +116,7 @@ WR_HD float wr_sin(float x) {
     float res = (j & 2) ? pc : ps;
     return u2f(f2u(res) ^ sign);
 }
+WR_HD float wr_sin(float x) { return wr_sin_t<true>(x); }
 
 // ---------------------------------------------------------------------------------------
 // Per-frame constants, passed to kernels by value.
@@ -550,41 +556,55 @@ WR_HD V4 fs_pbr(const FrameConsts& fc, const ShadowMap& sm, const uint32_t* texe
 // ---------------------------------------------------------------------------------------
 // Fog: noise.wgsl + fog.wgsl.
 
-WR_HD float hash_from_dot(float d) {  // noise.wgsl:4 after the dot product
-    float s = wr_sin(d) * 42123.45f;
+// noise.wgsl:4 after the dot product: fract(sin(d) * 42123.45) * 2 - 1.  fr * 2 is exact,
+// so the fused form rounds once exactly where the two-step form rounds.
+template <bool GUARD>
+WR_HD float hash_from_dot(float d) {
+    float s = wr_sin_t<GUARD>(d) * 42123.45f;
     float fr = s - floorf(s);
-    return fr * 2.0f - 1.0f;
+    return fmaf(fr, 2.0f, -1.0f);
 }
+// smoothstep(0, 1, v) = t*t*(3 - 2t); 2t is exact, so fma(-2, t, 3) equals 3 - 2*t bit for bit.
 WR_HD float smooth01(float v) {
     float t = fminf(fmaxf(v, 0.0f), 1.0f);
-    return (t * t) * (3.0f - 2.0f * t);
+    return (t * t) * fmaf(-2.0f, t, 3.0f);
 }
 // noise.wgsl:7-24.  The eight corner dot products (x*12.345 + y*67.89) + z*412.12 share
 // their six products and four x+y sums; every value is rounded exactly as when each
 // corner is evaluated on its own.
-WR_HD float value_noise(V3 p) {
+template <bool GUARD>
+WR_HD float value_noise_t(V3 p) {
     float ux = floorf(p.x), uy = floorf(p.y), uz = floorf(p.z);
     float sx = smooth01(p.x - ux), sy = smooth01(p.y - uy), sz = smooth01(p.z - uz);
     float x0 = ux * 12.345f, x1 = (ux + 1.0f) * 12.345f;
     float y0 = uy * 67.89f, y1 = (uy + 1.0f) * 67.89f;
     float z0 = uz * 412.12f, z1 = (uz + 1.0f) * 412.12f;
     float xy00 = x0 + y0, xy10 = x1 + y0, xy01 = x0 + y1, xy11 = x1 + y1;
-    float a = hash_from_dot(xy00 + z0), b = hash_from_dot(xy10 + z0);
-    float c = hash_from_dot(xy01 + z0), d = hash_from_dot(xy11 + z0);
-    float e = hash_from_dot(xy00 + z1), f = hash_from_dot(xy10 + z1);
-    float g = hash_from_dot(xy01 + z1), h = hash_from_dot(xy11 + z1);
+    float a = hash_from_dot<GUARD>(xy00 + z0), b = hash_from_dot<GUARD>(xy10 + z0);
+    float c = hash_from_dot<GUARD>(xy01 + z0), d = hash_from_dot<GUARD>(xy11 + z0);
+    float e = hash_from_dot<GUARD>(xy00 + z1), f = hash_from_dot<GUARD>(xy10 + z1);
+    float g = hash_from_dot<GUARD>(xy01 + z1), h = hash_from_dot<GUARD>(xy11 + z1);
     return mixf(mixf(mixf(a, b, sx), mixf(c, d, sx), sy), mixf(mixf(e, f, sx), mixf(g, h, sx), sy), sz);
 }
-// noise.wgsl:26-40
-WR_HD float fbm(V3 p) {
+WR_HD float value_noise(V3 p) { return value_noise_t<true>(p); }
+
+template <bool GUARD>
+WR_HD float fbm_t(V3 p) {
     float weight = 0.5f, ret = 0.0f;
     V3 q = p;
     for (int i = 0; i < 8; ++i) {
-        ret += weight * value_noise(q);
+        ret += weight * value_noise_t<GUARD>(q);
         q = q * 2.0f;
         weight *= 0.5f;
     }
     return saturatef(ret);
+}
+// noise.wgsl:26-40.  The last octave samples p*128 and every hash argument is at most
+// (|q|+1) * (12.345 + 67.89 + 412.12); for |p| < 16000 that stays below 2^30, the sine's
+// range guard can never fire and the unguarded instantiation is used.
+WR_HD float fbm(V3 p) {
+    if (fabsf(p.x) < 16000.0f && fabsf(p.y) < 16000.0f && fabsf(p.z) < 16000.0f) return fbm_t<false>(p);  // false for NaN
+    return fbm_t<true>(p);
 }
 // fog.wgsl:48-62
 WR_HD float fog_noise(const FrameConsts& fc, V3 pos) {

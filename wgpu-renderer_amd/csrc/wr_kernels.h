@@ -383,11 +383,12 @@ __global__ __launch_bounds__(1024) void k_scan(RasterWS ws) {
 // (pass.rs:118-126).  Otherwise depth test Less with depth write (state.rs:467,482): the
 // smallest (depth, id) key wins, ties go to the earlier draw.
 //
-// The bin's triangle list is consumed 256 records at a time, one record per thread, all
-// loads in flight together.  A triangle of at most 16x16 pixels with at most 64 pixels of
-// its box inside the bin is rasterised by the thread that fetched it (64 triangles per
-// wavefront in flight); larger ones are parked in LDS and then taken one per wavefront,
-// 64 lanes testing one 8x8 pixel block per step.
+// The bin's triangle list is consumed 1024 records at a time, one record per thread, all
+// loads in flight together.  A triangle of at most 64x64 pixels with at most
+// WR_RASTER_LANE_AREA pixels of its box inside the bin is rasterised by the thread that
+// fetched it (64 triangles per wavefront in flight, 32-bit stepped edge functions); larger
+// ones are queued in LDS and then taken one per wavefront, 64 lanes testing one 8x8 pixel
+// block per step with 64-bit edge functions.
 template <bool SHADOW>
 __device__ inline void raster_pixel(const Rec& r, const Edges& e, int px, int py, int ox, int oy,
                                     unsigned long long* tile, uint32_t* tile32) {
@@ -404,18 +405,25 @@ __device__ inline void raster_pixel(const Rec& r, const Edges& e, int px, int py
     }
 }
 
-template <bool SHADOW>
-__global__ __launch_bounds__(256) void k_raster(RasterWS ws, int W, int H, uint32_t* vis, float* depth,
-                                                int tile_rank, int tile_world) {
+#ifndef WR_RASTER_LANE_AREA
+#define WR_RASTER_LANE_AREA 128
+#endif
+// THREADS: 256 for the shadow faces (6144 mostly short lists: more bins in flight per CU),
+// 1024 for the colour target (few bins, some with thousands of triangles: 16 wavefronts
+// sharing the tile shorten the longest lists).
+template <bool SHADOW, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, uint32_t* vis, float* depth,
+                                                    int tile_rank, int tile_world) {
+    constexpr int kRasterThreads = THREADS;
     __shared__ unsigned long long tile[SHADOW ? 1 : kBin * kBin];
     __shared__ uint32_t tile32[SHADOW ? kBin * kBin : 1];
-    __shared__ Rec bigq[256];
+    __shared__ uint32_t bigq[kRasterThreads];  // record indices of the chunk's large triangles
     __shared__ uint32_t s_nbig;
     const int b = blockIdx.x, layer = blockIdx.y;
     if (!bin_owned(b, tile_rank, tile_world)) return;
     const int bx = b % ws.bins_x, by = b / ws.bins_x;
     const int ox = bx * kBin, oy = by * kBin;
-    for (int i = threadIdx.x; i < kBin * kBin; i += 256) {
+    for (int i = threadIdx.x; i < kBin * kBin; i += kRasterThreads) {
         if (SHADOW) tile32[i] = 0x3F800000u;
         else tile[i] = 0x3F800000FFFFFFFFull;
     }
@@ -424,18 +432,19 @@ __global__ __launch_bounds__(256) void k_raster(RasterWS ws, int W, int H, uint3
     const Rec* recs = ws.recs + (size_t)layer * ((size_t)ws.slots + ws.ovf_cap);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lx = lane & 7, ly = lane >> 3;
-    for (uint32_t c0 = 0; c0 < n; c0 += 256) {
+    for (uint32_t c0 = 0; c0 < n; c0 += kRasterThreads) {
         if (tid == 0) s_nbig = 0;
         __syncthreads();  // also orders the tile initialisation before the first atomics
         if (c0 + tid < n && off + c0 + tid < ws.items_cap) {
-            Rec r = load_rec(&recs[ws.bin_items[off + c0 + tid]]);
+            const uint32_t ri = ws.bin_items[off + c0 + tid];
+            Rec r = load_rec(&recs[ri]);
             int x0 = imax((int)(r.bbmin & 0xffffu), ox), x1 = imin((int)(r.bbmax & 0xffffu), ox + kBin - 1);
             int y0 = imax((int)(r.bbmin >> 16), oy), y1 = imin((int)(r.bbmax >> 16), oy + kBin - 1);
             const int fw = imax(r.X0, imax(r.X1, r.X2)) - imin(r.X0, imin(r.X1, r.X2));
             const int fh = imax(r.Y0, imax(r.Y1, r.Y2)) - imin(r.Y0, imin(r.Y1, r.Y2));
-            if (fw <= 16 * 256 && fh <= 16 * 256 && (x1 - x0 + 1) * (y1 - y0 + 1) <= 64) {
-                // The triangle's vertices span at most 16x16 pixels, so every edge function
-                // stays below 2^31 over its box and can be stepped in 32-bit integers; the
+            if (fw <= 64 * 256 && fh <= 64 * 256 && (x1 - x0 + 1) * (y1 - y0 + 1) <= WR_RASTER_LANE_AREA) {
+                // The triangle's vertices span at most 64x64 pixels, so every edge function
+                // stays below 2^30 over its box and can be stepped in 32-bit integers; the
                 // values are the same integers the 64-bit evaluation gives.
                 Edges e;
                 make_edges(r, e);
@@ -464,24 +473,24 @@ __global__ __launch_bounds__(256) void k_raster(RasterWS ws, int W, int H, uint3
                     r0 += dy0; r1 += dy1; r2 += dy2;
                 }
             } else {
-                bigq[atomicAdd(&s_nbig, 1u)] = r;
+                bigq[atomicAdd(&s_nbig, 1u)] = ri;
             }
         }
         __syncthreads();
         const uint32_t nbig = s_nbig;
-        for (uint32_t q = wave; q < nbig; q += 4) {
-            Rec r = bigq[q];
+        for (uint32_t q = wave; q < nbig; q += kRasterThreads / 64) {
+            // wave-uniform record: scalar loads, edge set-up on the scalar unit
+            const uint32_t ri = __builtin_amdgcn_readfirstlane(bigq[q]);
+            Rec r = load_rec(&recs[ri]);
             Edges e;
             make_edges(r, e);
-            int x0 = __builtin_amdgcn_readfirstlane(imax((int)(r.bbmin & 0xffffu), ox));
-            int x1 = __builtin_amdgcn_readfirstlane(imin((int)(r.bbmax & 0xffffu), ox + kBin - 1));
-            int y0 = __builtin_amdgcn_readfirstlane(imax((int)(r.bbmin >> 16), oy));
-            int y1 = __builtin_amdgcn_readfirstlane(imin((int)(r.bbmax >> 16), oy + kBin - 1));
+            int x0 = imax((int)(r.bbmin & 0xffffu), ox), x1 = imin((int)(r.bbmax & 0xffffu), ox + kBin - 1);
+            int y0 = imax((int)(r.bbmin >> 16), oy), y1 = imin((int)(r.bbmax >> 16), oy + kBin - 1);
             for (int qy = y0 >> 3; qy <= (y1 >> 3); ++qy)
                 for (int qx = x0 >> 3; qx <= (x1 >> 3); ++qx) {
                     int bx0 = imax(qx * 8, x0), bx1 = imin(qx * 8 + 7, x1);
                     int by0 = imax(qy * 8, y0), by1 = imin(qy * 8 + 7, y1);
-                    if (__builtin_amdgcn_readfirstlane((int)box_rejected(e, bx0, by0, bx1, by1))) continue;
+                    if (box_rejected(e, bx0, by0, bx1, by1)) continue;
                     int px = qx * 8 + lx, py = qy * 8 + ly;
                     if (px < x0 || px > x1 || py < y0 || py > y1) continue;
                     raster_pixel<SHADOW>(r, e, px, py, ox, oy, tile, tile32);
@@ -490,7 +499,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterWS ws, int W, int H, uint3
         __syncthreads();
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < kBin * kBin; i += 256) {
+    for (int i = threadIdx.x; i < kBin * kBin; i += kRasterThreads) {
         int px = ox + (i & (kBin - 1)), py = oy + (i / kBin);
         if (px >= W || py >= H) continue;
         size_t o = (size_t)layer * (size_t)W * (size_t)H + (size_t)py * W + px;
