@@ -15,6 +15,36 @@ float hc_fog_noise(const float* p, float time) {
     fc.time = time; fc.drift_xy = time * 0.2f; fc.drift_z = wr_sin(time * 0.1f) * 0.5f;
     return fog_noise(fc, v3(p[0], p[1], p[2]));
 }
+// fog_noise through hash tables built on the host for a box around p (every level whose
+// lattice box has at most `cap` entries), to compare with the direct evaluation.
+float hc_fog_noise_tab(const float* p, float time, int cap, int* tabled_levels) {
+    FrameConsts fc; memset(&fc, 0, sizeof(fc));
+    fc.time = time; fc.drift_xy = time * 0.2f; fc.drift_z = wr_sin(time * 0.1f) * 0.5f;
+    NoiseTables nt; memset(&nt, 0, sizeof(nt));
+    static float pool[1 << 16];
+    size_t used = 0; int nlev = 0;
+    const double drift[3] = {fc.drift_xy, fc.drift_xy, fc.drift_z};
+    for (int k = 0; k < 2; ++k) for (int o = 0; o < 8; ++o) {
+        double s = k == 0 ? 0.01 : 0.05, m = (double)(1 << o);
+        long l[3], n[3];
+        for (int r = 0; r < 3; ++r) {
+            double a = ((p[r] - 3.0) * s + drift[r]) * m, b = ((p[r] + 3.0) * s + drift[r]) * m;
+            l[r] = (long)floor(a) - 1; n[r] = (long)floor(b) + 2 - l[r] + 1;
+        }
+        size_t entries = (size_t)(n[0] * n[1] * n[2]);
+        if ((int)entries > cap || used + entries > sizeof(pool) / 4) continue;
+        NoiseTable& t = nt.level[k * 8 + o];
+        t.data = pool + used; t.lox = (int)l[0]; t.loy = (int)l[1]; t.loz = (int)l[2];
+        t.nx = (int)n[0]; t.ny = (int)n[1]; t.nz = (int)n[2];
+        for (size_t i = 0; i < entries; ++i) {
+            int ix = (int)(i % n[0]), iy = (int)((i / n[0]) % n[1]), iz = (int)(i / (n[0] * n[1]));
+            pool[used + i] = lattice_hash((float)(t.lox + ix), (float)(t.loy + iy), (float)(t.loz + iz));
+        }
+        used += entries; ++nlev;
+    }
+    *tabled_levels = nlev;
+    return fog_noise_tab(fc, nt, v3(p[0], p[1], p[2]));
+}
 void hc_brdf(const float* n, const float* l, const float* v, const float* h, const float* a, float rough, float metal, float* out) {
     V3 r = brdf(v3(n[0], n[1], n[2]), v3(l[0], l[1], l[2]), v3(v[0], v[1], v[2]), v3(h[0], h[1], h[2]), v3(a[0], a[1], a[2]), rough, metal);
     out[0] = r.x; out[1] = r.y; out[2] = r.z;

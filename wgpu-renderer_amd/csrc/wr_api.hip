@@ -31,6 +31,8 @@ static_assert(sizeof(WrCameraUniform) == 224, "CameraUniform layout (camera.rs:1
 static_assert(sizeof(WrLightUniform) == 416, "LightUniform layout (light.rs:11-18)");
 static_assert(sizeof(WrGlobalUniforms) == 16, "GlobalUniforms layout (state.rs:21-28)");
 static_assert(sizeof(WrMaterialUniform) == 16, "MaterialUniform layout (material.rs:13-18)");
+constexpr size_t kNoiseLevelEntries = 2u << 20;  // largest hash table of one noise level
+constexpr size_t kNoisePoolEntries = 4u << 20;   // all levels together (16 MB)
 static_assert(sizeof(FrameConsts) < 3072, "FrameConsts must fit the kernel argument segment");
 
 namespace {
@@ -87,6 +89,8 @@ struct WrContext {
     float* d_shadow = nullptr;
     unsigned long long* d_counters = nullptr;
     uint8_t* d_rp_flag = nullptr;    // [H][W] pixels flagged for ordered blending
+    float* d_noise_pool = nullptr;   // hash tables of the low noise octaves, rebuilt every frame
+    float fog_aabb[6] = {0, 0, 0, 0, 0, 0};  // fog model bounds in model space (min xyz, max xyz)
     uint32_t* d_fog_pixel = nullptr; // [W*H] fog march work items: pixel index
     float4* d_fog_ray = nullptr;     // [W*H] ray origin + max_fog_depth
     uint32_t* d_err = nullptr;  // [0] error bits, [1] geometry bin items, [2] shadow bin items, [3] fog (unused)
@@ -213,6 +217,16 @@ int build_scene(WrContext* ctx) {
         WR_HIP(hipMemcpy(d.idx, h.idx.data(), sizeof(uint32_t) * h.idx.size(), hipMemcpyHostToDevice));
         WR_HIP(hipMemcpy(d.tri_mat, h.tri_mat.data(), sizeof(uint32_t) * d.ntris, hipMemcpyHostToDevice));
     }
+    {
+        const ModelHost& fh = ctx->host[WR_MODEL_FOG_VOLUME];
+        for (int k = 0; k < 3; ++k) { ctx->fog_aabb[k] = 0.0f; ctx->fog_aabb[3 + k] = 0.0f; }
+        for (size_t i = 0; i < fh.verts.size(); ++i)
+            for (int k = 0; k < 3; ++k) {
+                float v = fh.verts[i].position[k];
+                if (i == 0 || v < ctx->fog_aabb[k]) ctx->fog_aabb[k] = v;
+                if (i == 0 || v > ctx->fog_aabb[3 + k]) ctx->fog_aabb[3 + k] = v;
+            }
+    }
     // textures: one texel pool
     {
         std::vector<TexDesc> descs;
@@ -331,6 +345,47 @@ int shadow_stage(WrContext* ctx, const FrameConsts& fc) {
     return bin_and_raster(ctx, ctx->shadow, true, 0, 1);
 }
 
+// Chooses which noise levels get a hash table this frame.  Every march sample lies within
+// the fog volume's world box grown by the longest march (30*5 + 10*10 units); a level is
+// tabled when its lattice over that box fits the per-level and pool budgets.  Samples that
+// still fall outside (they cannot, short of non-finite inputs) are evaluated directly.
+NoiseTables plan_noise_tables(const WrContext* ctx, const FrameConsts& fc, uint32_t* max_entries) {
+    NoiseTables nt;
+    memset(&nt, 0, sizeof(nt));
+    *max_entries = 0;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int c = 0; c < 8; ++c) {
+        double p[3] = {ctx->fog_aabb[(c & 1) ? 3 : 0], ctx->fog_aabb[(c & 2) ? 4 : 1], ctx->fog_aabb[(c & 4) ? 5 : 2]};
+        for (int r = 0; r < 3; ++r) {
+            double w = fc.model_fog[r] * p[0] + fc.model_fog[4 + r] * p[1] + fc.model_fog[8 + r] * p[2] + fc.model_fog[12 + r];
+            if (!(std::fabs(w) < 1e7)) return nt;
+            lo[r] = std::min(lo[r], w); hi[r] = std::max(hi[r], w);
+        }
+    }
+    const double grow = 30 * 5.0 + 10 * 10.0 + 2.0;
+    const double drift[3] = {fc.drift_xy, fc.drift_xy, fc.drift_z};
+    size_t used = 0;
+    for (int k = 0; k < 2; ++k)
+        for (int o = 0; o < 8; ++o) {
+            const double s = (k == 0 ? 0.01 : 0.05), m = (double)(1 << o);
+            long l[3], n[3];
+            for (int r = 0; r < 3; ++r) {
+                double a = ((lo[r] - grow) * s + drift[r]) * m, b = ((hi[r] + grow) * s + drift[r]) * m;
+                l[r] = (long)std::floor(a) - 1;
+                n[r] = (long)std::floor(b) + 2 - l[r] + 1;
+            }
+            double entries = (double)n[0] * n[1] * n[2];
+            if (entries > (double)kNoiseLevelEntries || used + (size_t)entries > kNoisePoolEntries) continue;
+            NoiseTable& t = nt.level[k * 8 + o];
+            t.data = ctx->d_noise_pool + used;
+            t.lox = (int)l[0]; t.loy = (int)l[1]; t.loz = (int)l[2];
+            t.nx = (int)n[0]; t.ny = (int)n[1]; t.nz = (int)n[2];
+            used += (size_t)entries;
+            *max_entries = std::max<uint32_t>(*max_entries, (uint32_t)entries);
+        }
+    return nt;
+}
+
 int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do_shadow) {
     const ModelDev& g = ctx->dev[WR_MODEL_GEOMETRY];
     const ModelDev& lm = ctx->dev[WR_MODEL_LIGHT_MARKER];
@@ -382,6 +437,10 @@ int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do
         fa.counters = ctx->d_counters;
         // the fog workspace has one bin, so its bin_count word is free: it counts march items
         fa.item_count = ctx->fog.ws.bin_count; fa.item_pixel = ctx->d_fog_pixel; fa.item_ray = ctx->d_fog_ray;
+        uint32_t max_entries = 0;
+        fa.tables_noise = plan_noise_tables(ctx, fc, &max_entries);
+        if (max_entries)
+            hipLaunchKernelGGL(k_fog_tables, dim3((max_entries + 255u) / 256u, 16, 1), dim3(256), 0, ctx->stream, fa.tables_noise);
         dim3 mg((uint32_t)(((size_t)ctx->W * ctx->H + 63) / 64), 1, 1);
         if (ctx->counting) {
             hipLaunchKernelGGL(k_fog_setup<true>, pg, dim3(256), 0, ctx->stream, fa);
@@ -446,6 +505,7 @@ int wr_create(const WrConfig* config, WrContext** out_ctx) {
         WR_HIP(hipMemcpy(ctx->d_tables, tables, sizeof(tables), hipMemcpyHostToDevice));
         WR_HIP(hipMalloc(&ctx->d_counters, 8 * sizeof(unsigned long long)));
         WR_HIP(hipMemset(ctx->d_counters, 0, 8 * sizeof(unsigned long long)));
+        WR_HIP(hipMalloc(&ctx->d_noise_pool, kNoisePoolEntries * sizeof(float)));
         WR_HIP(hipMalloc(&ctx->d_err, 4 * sizeof(uint32_t)));
         WR_HIP(hipMemset(ctx->d_err, 0, 4 * sizeof(uint32_t)));
         size_t ns = (size_t)6 * S * S;
@@ -466,7 +526,7 @@ void wr_destroy(WrContext* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_scene(ctx);
     free_targets(ctx);
-    dfree(ctx->d_tables); dfree(ctx->d_counters); dfree(ctx->d_err); dfree(ctx->d_shadow);
+    dfree(ctx->d_tables); dfree(ctx->d_counters); dfree(ctx->d_err); dfree(ctx->d_shadow); dfree(ctx->d_noise_pool);
     for (int f = 0; f < WrContext::kEvFrames; ++f)
         for (int i = 0; i < 5; ++i) if (ctx->ev[f][i]) (void)hipEventDestroy(ctx->ev[f][i]);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

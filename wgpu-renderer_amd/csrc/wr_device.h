@@ -588,12 +588,57 @@ WR_HD float value_noise_t(V3 p) {
 }
 WR_HD float value_noise(V3 p) { return value_noise_t<true>(p); }
 
+// Per-frame hash tables for the low-frequency octaves.  The hash of a lattice point depends
+// only on its integer coordinates, so for an octave whose lattice over the fog region is
+// small it is computed once per frame (k_fog_tables) and the march reads the eight corner
+// hashes instead of evaluating eight sines.  An entry holds exactly hash_from_dot of the
+// spec's dot product for that lattice point, so a table hit and a direct evaluation give
+// the same bits; a sample outside the table's box falls back to the direct evaluation.
+struct NoiseTable {
+    const float* data;   // nullptr: level not tabled
+    int lox, loy, loz;   // lattice coordinate of entry (0,0,0)
+    int nx, ny, nz;
+};
+struct NoiseTables { NoiseTable level[16]; };  // [fbm index * 8 + octave]
+
+WR_HD float lattice_hash(float ux, float uy, float uz) {  // rand(u) of noise.wgsl:3-5 for integer u
+    return hash_from_dot<true>((ux * 12.345f + uy * 67.89f) + uz * 412.12f);
+}
+
+template <bool GUARD>
+WR_HD float value_noise_tab(V3 p, const NoiseTable& t) {
+    float ux = floorf(p.x), uy = floorf(p.y), uz = floorf(p.z);
+    // |u| < 2^24 here (the caller bounds |p|), so the conversions are exact
+    int ix = (int)ux - t.lox, iy = (int)uy - t.loy, iz = (int)uz - t.loz;
+    if (t.data != nullptr && (unsigned)ix < (unsigned)(t.nx - 1) && (unsigned)iy < (unsigned)(t.ny - 1) &&
+        (unsigned)iz < (unsigned)(t.nz - 1)) {
+        float sx = smooth01(p.x - ux), sy = smooth01(p.y - uy), sz = smooth01(p.z - uz);
+        const float* q = t.data + ((size_t)iz * t.ny + iy) * t.nx + ix;
+        const size_t sy_ = (size_t)t.nx, sz_ = (size_t)t.nx * t.ny;
+        float a = q[0], b = q[1], c = q[sy_], d = q[sy_ + 1];
+        float e = q[sz_], f = q[sz_ + 1], g = q[sz_ + sy_], h = q[sz_ + sy_ + 1];
+        return mixf(mixf(mixf(a, b, sx), mixf(c, d, sx), sy), mixf(mixf(e, f, sx), mixf(g, h, sx), sy), sz);
+    }
+    return value_noise_t<GUARD>(p);
+}
+
 template <bool GUARD>
 WR_HD float fbm_t(V3 p) {
     float weight = 0.5f, ret = 0.0f;
     V3 q = p;
     for (int i = 0; i < 8; ++i) {
         ret += weight * value_noise_t<GUARD>(q);
+        q = q * 2.0f;
+        weight *= 0.5f;
+    }
+    return saturatef(ret);
+}
+template <bool GUARD>
+WR_HD float fbm_tab_t(V3 p, const NoiseTable* tabs) {
+    float weight = 0.5f, ret = 0.0f;
+    V3 q = p;
+    for (int i = 0; i < 8; ++i) {
+        ret += weight * value_noise_tab<GUARD>(q, tabs[i]);
         q = q * 2.0f;
         weight *= 0.5f;
     }
@@ -606,6 +651,10 @@ WR_HD float fbm(V3 p) {
     if (fabsf(p.x) < 16000.0f && fabsf(p.y) < 16000.0f && fabsf(p.z) < 16000.0f) return fbm_t<false>(p);  // false for NaN
     return fbm_t<true>(p);
 }
+WR_HD float fbm_tab(V3 p, const NoiseTable* tabs) {
+    if (fabsf(p.x) < 16000.0f && fabsf(p.y) < 16000.0f && fabsf(p.z) < 16000.0f) return fbm_tab_t<false>(p, tabs);
+    return fbm_t<true>(p);
+}
 // fog.wgsl:48-62
 WR_HD float fog_noise(const FrameConsts& fc, V3 pos) {
     V3 p1 = pos * 0.01f;
@@ -616,15 +665,26 @@ WR_HD float fog_noise(const FrameConsts& fc, V3 pos) {
     float n2 = fbm(p2);
     return (0.8f * n1 + 0.15f * n2) + 0.05f;
 }
-// fog.wgsl:64-85.  Returns (density, depth); `evals` counts fog_noise calls.
-WR_HD V2 ray_march(const FrameConsts& fc, V3 origin, V3 dir, float max_depth, int max_steps, float step_size,
-                   float fog_density, uint32_t& evals) {
+WR_HD float fog_noise_tab(const FrameConsts& fc, const NoiseTables& nt, V3 pos) {
+    V3 p1 = pos * 0.01f;
+    p1.x += fc.drift_xy; p1.y += fc.drift_xy; p1.z += fc.drift_z;
+    float n1 = fbm_tab(p1, nt.level);
+    V3 p2 = pos * 0.05f;
+    p2.x += fc.drift_xy; p2.y += fc.drift_xy; p2.z += fc.drift_z;
+    float n2 = fbm_tab(p2, nt.level + 8);
+    return (0.8f * n1 + 0.15f * n2) + 0.05f;
+}
+// fog.wgsl:64-85.  Returns (density, depth); `evals` counts fog_noise calls.  nt == nullptr
+// evaluates every hash directly.
+WR_HD V2 ray_march(const FrameConsts& fc, const NoiseTables* nt, V3 origin, V3 dir, float max_depth, int max_steps,
+                   float step_size, float fog_density, uint32_t& evals) {
     float density = 0.0f, depth = 0.0f;
     float contribution = fog_density / (float)max_steps;
     for (int i = 0; i < max_steps; ++i) {
         depth += step_size;
         if (depth >= max_depth) break;
-        float noise = fog_noise(fc, origin + dir * depth);
+        V3 pos = origin + dir * depth;
+        float noise = nt ? fog_noise_tab(fc, *nt, pos) : fog_noise(fc, pos);
         ++evals;
         density += noise * contribution;
         if (density >= 1.0f) { density = 1.0f; break; }
@@ -655,17 +715,18 @@ WR_HD float fog_max_depth(const FrameConsts& fc, const float* depth_tex, float f
 
 // fog.wgsl:127-128,138-165 (ray_march_fog 87-116 inlined): the march and the fog colour for
 // a fragment whose max_fog_depth is positive.
-WR_HD V4 fog_march_shade(const FrameConsts& fc, const ShadowMap& sm, V3 origin, float max_fog_depth, uint32_t& evals) {
+WR_HD V4 fog_march_shade(const FrameConsts& fc, const ShadowMap& sm, const NoiseTables* nt, V3 origin, float max_fog_depth,
+                         uint32_t& evals) {
     V3 cam = v3(fc.cam_pos[0], fc.cam_pos[1], fc.cam_pos[2]);
     V3 lp = v3(fc.light_pos[0], fc.light_pos[1], fc.light_pos[2]);
     V3 direction = normalize3(origin - cam);
-    V2 fm = ray_march(fc, origin, direction, max_fog_depth, 30, 5.0f, 2.0f, evals);
+    V2 fm = ray_march(fc, nt, origin, direction, max_fog_depth, 30, 5.0f, 2.0f, evals);
     float fog_density = fm.x, fog_depth = fm.y;
     V3 fog_end = origin + direction * fog_depth;
     V3 to_light = lp - fog_end;
     float max_light_dist = length3(to_light);
     V3 light_direction = to_light / max_light_dist;
-    V2 lm = ray_march(fc, fog_end, light_direction, max_light_dist, 10, 10.0f, 3.0f, evals);
+    V2 lm = ray_march(fc, nt, fog_end, light_direction, max_light_dist, 10, 10.0f, 3.0f, evals);
     float occlusion = lm.x;
 
     V3 fog_position = origin + direction * fog_depth;

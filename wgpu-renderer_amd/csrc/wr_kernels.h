@@ -818,6 +818,7 @@ struct FogArgs {
     uint32_t* item_count;  // march work items appended this frame
     uint32_t* item_pixel;  // [W*H] pixel index of each item
     float4* item_ray;      // [W*H] ray origin xyz + max_fog_depth
+    NoiseTables tables_noise;  // hash tables of the low octaves (k_fog_tables)
 };
 
 // One fog fragment: interpolate the world position, run the pre-march part of fog.wgsl's
@@ -900,7 +901,7 @@ __global__ __launch_bounds__(256) void k_fog_setup(FogArgs a) {
                 float md;
                 if (!fog_fragment(a, r, beta, t, px, py, zbuf, o, md)) continue;
                 uint32_t evals = 0;
-                V4 src = md <= 0.0f ? V4{0.0f, 0.0f, 0.0f, 0.0f} : fog_march_shade(a.fc, sm, o, md, evals);
+                V4 src = md <= 0.0f ? V4{0.0f, 0.0f, 0.0f, 0.0f} : fog_march_shade(a.fc, sm, nullptr, o, md, evals);
                 if (COUNT) { atomicAdd(&a.counters[0], 1ull); atomicAdd(&a.counters[1], (unsigned long long)evals); }
                 col = blend_pack(ct, col, src, true);
             }
@@ -921,6 +922,17 @@ __global__ __launch_bounds__(256) void k_fog_setup(FogArgs a) {
     }
 }
 
+// Fills the hash table of one noise level: entry (i,j,k) = hash of lattice point lo + (i,j,k).
+__global__ __launch_bounds__(256) void k_fog_tables(NoiseTables nt) {
+    const NoiseTable t = nt.level[blockIdx.y];
+    if (t.data == nullptr) return;
+    const size_t n = (size_t)t.nx * t.ny * t.nz;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int ix = (int)(i % (size_t)t.nx), iy = (int)((i / (size_t)t.nx) % (size_t)t.ny), iz = (int)(i / ((size_t)t.nx * t.ny));
+    const_cast<float*>(t.data)[i] = lattice_hash((float)(t.lox + ix), (float)(t.loy + iy), (float)(t.loz + iz));
+}
+
 // Fog pass, part 2: one thread per work item runs both marches of fog.wgsl and blends the
 // fog colour over the pixel (SrcAlpha / OneMinusSrcAlpha, state.rs:501).  One wavefront per
 // workgroup, all lanes busy, so the long-running marches spread evenly over the chip.
@@ -933,7 +945,7 @@ __global__ __launch_bounds__(64) void k_fog_march(FogArgs a) {
     ColorTables ct{a.tables};
     ShadowMap sm{a.shadow, a.fc.S};
     uint32_t evals = 0;
-    V4 src = fog_march_shade(a.fc, sm, v3(ray.x, ray.y, ray.z), ray.w, evals);
+    V4 src = fog_march_shade(a.fc, sm, &a.tables_noise, v3(ray.x, ray.y, ray.z), ray.w, evals);
     if (COUNT) atomicAdd(&a.counters[1], (unsigned long long)evals);
     a.color[pi] = blend_pack(ct, a.color[pi], src, true);
 }
