@@ -36,7 +36,8 @@ def render_gpu(sc, cam, light, glob, passes, w, h, s, counting=False, **kw):
         out["shadow"] = r.read_shadow_map()
     if counting:
         st = r.stats()
-        out["counters"] = dict(fog_fragments=int(st.fog_fragments), fog_noise_evals=int(st.fog_noise_evals))
+        out["counters"] = dict(fog_fragments=int(st.fog_fragments), fog_noise_evals=int(st.fog_noise_evals),
+                               replay_pixels=int(st.replay_pixels), replay_slow_pixels=int(st.replay_slow_pixels))
     r.close()
     return out
 
@@ -200,6 +201,32 @@ def test_ordered_blending_follows_draw_order(order):
     assert np.array_equal(g["color"], o["color"])  # blending is 8-bit round trips: exact
     assert o["counters"]["blended_lt1"] > 1000
     assert (o["color"][..., 3] < 255).any()  # alpha is blended too (pass.rs:79-82)
+
+
+def test_ordered_blending_many_layers():
+    """More translucent layers on a pixel than the per-pixel fragment list holds (16): those
+    pixels go through the general replay, the others through the list path; both must agree
+    with the oracle exactly."""
+    w, h, s = 200, 150, 64
+    base = blend_order_scene((0,))
+    rng = np.random.default_rng(11)
+    order = rng.permutation(22)
+    meshes = [base.geometry.meshes[0]]
+    for k in order:
+        x0 = -250 + 12 * int(k)
+        q, idx = _quad(x0, x0 + 260, -180 + 5 * int(k), 150, -90.0 + 4.0 * int(k), 2.0)
+        meshes.append(scene.Mesh(q, idx, 1 + int(k) % 2))
+    sc = scene.Scene(base.textures, scene.Model(meshes, base.geometry.materials), base.fog, base.marker,
+                     base.geometry_instance, base.fog_instance)
+    cam = abi.camera_uniform((0.0, 0.0, 500.0), 0.0, -90.0, 55.0, w, h)
+    light = abi.light_uniform((0.0, 100.0, 300.0), (1.0, 1.0, 1.0, 250000.0))
+    glob = abi.global_uniforms(1.0, 0)
+    g = render_gpu(sc, cam, light, glob, abi.PASS_LIGHT_DEBUG, w, h, s, counting=True)
+    o = render_oracle(sc, cam, light, glob, abi.PASS_LIGHT_DEBUG, w, h, s, threads=2)
+    assert_parity(g, o)
+    assert np.array_equal(g["color"], o["color"])
+    assert g["counters"]["replay_slow_pixels"] > 100
+    assert g["counters"]["replay_pixels"] > g["counters"]["replay_slow_pixels"]
 
 
 def test_draw_orders_give_different_images():

@@ -88,7 +88,8 @@ struct WrContext {
     uint32_t* d_color = nullptr;
     float* d_shadow = nullptr;
     unsigned long long* d_counters = nullptr;
-    uint8_t* d_rp_flag = nullptr;    // [H][W] pixels flagged for ordered blending
+    BlendWS blend{};                 // ordered-blend work space, sized with the colour target
+    size_t blend_clear_bytes = 0;    // counts + bin flags, cleared every frame
     float* d_noise_pool = nullptr;   // hash tables of the low noise octaves, rebuilt every frame
     float fog_aabb[6] = {0, 0, 0, 0, 0, 0};  // fog model bounds in model space (min xyz, max xyz)
     uint32_t* d_fog_pixel = nullptr; // [W*H] fog march work items: pixel index
@@ -153,7 +154,11 @@ int alloc_ws(WrContext* ctx, WsAlloc& w, uint32_t slots, uint32_t ovf_cap, uint3
 }
 
 void free_targets(WrContext* c) {
-    dfree(c->d_vis); dfree(c->d_depth); dfree(c->d_color); dfree(c->d_rp_flag); dfree(c->d_fog_pixel); dfree(c->d_fog_ray);
+    dfree(c->d_vis); dfree(c->d_depth); dfree(c->d_color); dfree(c->d_fog_pixel); dfree(c->d_fog_ray);
+    BlendWS& b = c->blend;
+    dfree(b.rp_slot); dfree(b.slot_pixel); dfree(b.counts); dfree(b.lists); dfree(b.list_count);
+    dfree(b.slow_slots); dfree(b.slot_frags); dfree(b.frag_item); dfree(b.frag_src);
+    b = BlendWS();
 }
 void free_scene(WrContext* c) {
     for (int m = 0; m < 3; ++m) {
@@ -173,10 +178,26 @@ int alloc_targets(WrContext* ctx) {
     WR_HIP(hipMalloc(&ctx->d_vis, n * 4));
     WR_HIP(hipMalloc(&ctx->d_depth, n * 4));
     WR_HIP(hipMalloc(&ctx->d_color, n * 4));
-    WR_HIP(hipMalloc(&ctx->d_rp_flag, n));
+    // Ordered blending: every pixel can be flagged, and every flagged pixel keeps up to
+    // kReplayK covering fragments (128 bytes per pixel of the target; only flagged pixels'
+    // lists are ever touched).
+    BlendWS& b = ctx->blend;
+    const size_t nbins = (size_t)((ctx->W + kBin - 1) / kBin) * (size_t)((ctx->H + kBin - 1) / kBin);
+    b.cap = (uint32_t)n; b.frag_cap = (uint32_t)n;
+    ctx->blend_clear_bytes = sizeof(uint32_t) * (4 + nbins);
+    WR_HIP(hipMalloc(&b.rp_slot, n * 4));
+    WR_HIP(hipMalloc(&b.slot_pixel, n * 4));
+    WR_HIP(hipMalloc(&b.counts, ctx->blend_clear_bytes));
+    b.bin_flag = b.counts + 4;
+    WR_HIP(hipMalloc(&b.lists, n * kReplayK * sizeof(uint2)));
+    WR_HIP(hipMalloc(&b.list_count, n * 4));
+    WR_HIP(hipMalloc(&b.slow_slots, n * 4));
+    WR_HIP(hipMalloc(&b.slot_frags, n * sizeof(uint2)));
+    WR_HIP(hipMalloc(&b.frag_item, n * sizeof(uint2)));
+    WR_HIP(hipMalloc(&b.frag_src, n * sizeof(float4)));
+    WR_HIP(hipMemset(b.rp_slot, 0, n * 4));
     WR_HIP(hipMalloc(&ctx->d_fog_pixel, n * 4));
     WR_HIP(hipMalloc(&ctx->d_fog_ray, n * sizeof(float4)));
-    WR_HIP(hipMemset(ctx->d_rp_flag, 0, n));
     WR_HIP(hipMemset(ctx->d_color, 0, n * 4));
     return WR_OK;
 }
@@ -330,9 +351,11 @@ int bin_and_raster(WrContext* ctx, WsAlloc& w, bool shadow, int tr, int tw) {
     hipLaunchKernelGGL(k_bin_fill, grid1(nrec, ws.layers), dim3(256), 0, ctx->stream, ws, tr, tw);
     dim3 g((uint32_t)(ws.bins_x * ws.bins_y), (uint32_t)ws.layers, 1);
     if (shadow)
-        hipLaunchKernelGGL((k_raster<true, 256>), g, dim3(256), 0, ctx->stream, ws, ctx->S, ctx->S, (uint32_t*)nullptr, ctx->d_shadow, 0, 1);
+        hipLaunchKernelGGL((k_raster<kRasterShadow, 256>), g, dim3(256), 0, ctx->stream, ws, ctx->S, ctx->S, (uint32_t*)nullptr,
+                           ctx->d_shadow, 0, 1, LayerSink{});
     else
-        hipLaunchKernelGGL((k_raster<false, 1024>), g, dim3(1024), 0, ctx->stream, ws, ctx->W, ctx->H, ctx->d_vis, ctx->d_depth, tr, tw);
+        hipLaunchKernelGGL((k_raster<kRasterColor, 1024>), g, dim3(1024), 0, ctx->stream, ws, ctx->W, ctx->H, ctx->d_vis,
+                           ctx->d_depth, tr, tw, LayerSink{});
     return WR_OK;
 }
 
@@ -416,14 +439,24 @@ int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do
     sa.v0 = ctx->vout.v0; sa.v1 = ctx->vout.v1; sa.v2 = ctx->vout.v2; sa.v3 = ctx->vout.v3;
     sa.mats = ctx->d_mats; sa.tex = ctx->d_tex; sa.texels = ctx->d_texels; sa.tables = ctx->d_tables;
     sa.shadow = ctx->d_shadow; sa.counters = ctx->d_counters;
-    sa.rp_flag = ctx->d_rp_flag;
+    sa.bw = ctx->blend;
+    WR_HIP(hipMemsetAsync(ctx->blend.counts, 0, ctx->blend_clear_bytes, ctx->stream));
     dim3 pg((uint32_t)(ctx->W + 15) / 16, (uint32_t)(ctx->H + 15) / 16, 1);
-    if (ctx->counting) {
-        hipLaunchKernelGGL(k_shade<true>, pg, dim3(256), 0, ctx->stream, sa);
-        hipLaunchKernelGGL(k_replay<true>, pg, dim3(256), 0, ctx->stream, sa);
-    } else {
-        hipLaunchKernelGGL(k_shade<false>, pg, dim3(256), 0, ctx->stream, sa);
-        hipLaunchKernelGGL(k_replay<false>, pg, dim3(256), 0, ctx->stream, sa);
+    if (ctx->counting) hipLaunchKernelGGL(k_shade<true>, pg, dim3(256), 0, ctx->stream, sa);
+    else hipLaunchKernelGGL(k_shade<false>, pg, dim3(256), 0, ctx->stream, sa);
+    // ordered blending of the pixels k_shade flagged: collect, order, shade, blend
+    {
+        const RasterWS& ws = ctx->geom.ws;
+        LayerSink ls{ctx->blend.rp_slot, ctx->blend.bin_flag, ctx->blend.lists, ctx->blend.list_count};
+        hipLaunchKernelGGL((k_raster<kRasterLayers, 1024>), dim3((uint32_t)(ws.bins_x * ws.bins_y), 1, 1), dim3(1024), 0,
+                           ctx->stream, ws, ctx->W, ctx->H, (uint32_t*)nullptr, (float*)nullptr, fc.tile_rank, fc.tile_world, ls);
+        const size_t npx = (size_t)ctx->W * ctx->H;
+        const uint32_t slot_groups = (uint32_t)std::min<size_t>((npx + 255) / 256, 2048);
+        hipLaunchKernelGGL(k_resolve, dim3(slot_groups), dim3(256), 0, ctx->stream, sa);
+        if (ctx->counting) hipLaunchKernelGGL(k_replay_slow<true>, dim3(256), dim3(64), 0, ctx->stream, sa);
+        else hipLaunchKernelGGL(k_replay_slow<false>, dim3(256), dim3(64), 0, ctx->stream, sa);
+        hipLaunchKernelGGL(k_shade_frags, dim3((uint32_t)std::min<size_t>((npx + 63) / 64, 16384)), dim3(64), 0, ctx->stream, sa);
+        hipLaunchKernelGGL(k_blend, dim3(slot_groups), dim3(256), 0, ctx->stream, sa);
     }
     if (prof) WR_HIP(hipEventRecord(ev[3], ctx->stream));
 

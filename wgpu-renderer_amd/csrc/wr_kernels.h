@@ -5,7 +5,8 @@
 //              -> k_raster<true>            (6 cube faces as grid.y "layers")
 //   geometry : k_vs_geometry -> k_setup<false> (+ k_setup_small for the light marker)
 //              -> k_scan -> k_bin_fill -> k_raster<false>   (visibility + depth buffers)
-//   shade    : k_shade -> k_replay          (deferred pbr.wgsl fragment stage; ordered blending)
+//   shade    : k_shade -> k_raster<layers> -> k_resolve -> k_shade_frags -> k_blend
+//              (deferred pbr.wgsl fragment stage; ordered blending of translucent fronts)
 //   fog      : k_setup_small(fog) -> k_fog_setup -> k_fog_march   (fog.wgsl fragment stage)
 //
 // The rasteriser is tile-binned: the target is cut into 64x64-pixel bins, every set-up
@@ -379,9 +380,11 @@ __global__ __launch_bounds__(1024) void k_scan(RasterWS ws) {
 
 // ------------------------------------------------------------------ rasteriser
 // One workgroup per (bin, layer) resolves the bin in an LDS tile and writes it out once.
-// SHADOW: depth-only, LessEqual with bias -> plain min of the biased depth
-// (pass.rs:118-126).  Otherwise depth test Less with depth write (state.rs:467,482): the
-// smallest (depth, id) key wins, ties go to the earlier draw.
+// kRasterShadow: depth-only, LessEqual with bias -> plain min of the biased depth
+// (pass.rs:118-126).  kRasterColor: depth test Less with depth write (state.rs:467,482): the
+// smallest (depth, id) key wins, ties go to the earlier draw.  kRasterLayers: second walk
+// over the colour target's bins that hold pixels flagged for ordered blending; every
+// fragment covering such a pixel is appended to the pixel's list.
 //
 // The bin's triangle list is consumed 1024 records at a time, one record per thread, all
 // loads in flight together.  A triangle of at most 64x64 pixels with at most
@@ -389,20 +392,44 @@ __global__ __launch_bounds__(1024) void k_scan(RasterWS ws) {
 // fetched it (64 triangles per wavefront in flight, 32-bit stepped edge functions); larger
 // ones are queued in LDS and then taken one per wavefront, 64 lanes testing one 8x8 pixel
 // block per step with 64-bit edge functions.
-template <bool SHADOW>
+constexpr int kRasterColor = 0, kRasterShadow = 1, kRasterLayers = 2;
+constexpr int kReplayK = 16;  // covering fragments kept per flagged pixel before the slow path
+
+// Where k_raster<kRasterLayers> puts the fragments of pixels flagged for ordered blending.
+struct LayerSink {
+    const uint32_t* rp_slot;   // [H][W] list slot + 1 of a flagged pixel, else 0
+    const uint32_t* bin_flag;  // [bins] non-zero: the bin holds a flagged pixel
+    uint2* lists;              // [slots][kReplayK] (id, depth bits)
+    uint32_t* list_count;      // [slots] fragments seen (may exceed kReplayK)
+};
+
+// One covered sample.  Colour: depth test Less with depth write, the smallest (depth, id)
+// key wins.  Shadow: min of the biased depth.  Layers: a flagged pixel's tile word holds
+// its list slot + 1 in the low half and the fragments seen so far in the high half.
+template <int MODE>
+__device__ inline void raster_emit(const Rec& r, float z, int li, unsigned long long* tile, uint32_t* tile32,
+                                   const LayerSink& ls) {
+    if (MODE == kRasterShadow) {
+        float zb = fminf(fmaxf(z + r.iw0, 0.0f), 1.0f);
+        atomicMin(&tile32[li], f2u(zb));
+    } else if (MODE == kRasterColor) {
+        if (z < 1.0f) atomicMin(&tile[li], ((unsigned long long)f2u(z) << 32) | (unsigned long long)r.id);
+    } else {
+        if (reinterpret_cast<const uint32_t*>(tile)[2 * li] == 0u) return;
+        unsigned long long old = atomicAdd(&tile[li], 1ull << 32);
+        uint32_t c = (uint32_t)(old >> 32);
+        if (c < (uint32_t)kReplayK) ls.lists[(size_t)((uint32_t)old - 1u) * kReplayK + c] = make_uint2(r.id, f2u(z));
+    }
+}
+
+template <int MODE>
 __device__ inline void raster_pixel(const Rec& r, const Edges& e, int px, int py, int ox, int oy,
-                                    unsigned long long* tile, uint32_t* tile32) {
+                                    unsigned long long* tile, uint32_t* tile32, const LayerSink& ls) {
     int64_t E[3];
     edge_eval(e, px, py, E);
     if (!edges_inside(e, E)) return;
     float z = depth_at(r, E);
-    int li = (py - oy) * kBin + (px - ox);
-    if (SHADOW) {
-        float zb = fminf(fmaxf(z + r.iw0, 0.0f), 1.0f);
-        atomicMin(&tile32[li], f2u(zb));
-    } else {
-        if (z < 1.0f) atomicMin(&tile[li], ((unsigned long long)f2u(z) << 32) | (unsigned long long)r.id);
-    }
+    raster_emit<MODE>(r, z, (py - oy) * kBin + (px - ox), tile, tile32, ls);
 }
 
 #ifndef WR_RASTER_LANE_AREA
@@ -411,21 +438,38 @@ __device__ inline void raster_pixel(const Rec& r, const Edges& e, int px, int py
 // THREADS: 256 for the shadow faces (6144 mostly short lists: more bins in flight per CU),
 // 1024 for the colour target (few bins, some with thousands of triangles: 16 wavefronts
 // sharing the tile shorten the longest lists).
-template <bool SHADOW, int THREADS>
+template <int MODE, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, uint32_t* vis, float* depth,
-                                                    int tile_rank, int tile_world) {
+                                                    int tile_rank, int tile_world, LayerSink ls) {
     constexpr int kRasterThreads = THREADS;
-    __shared__ unsigned long long tile[SHADOW ? 1 : kBin * kBin];
-    __shared__ uint32_t tile32[SHADOW ? kBin * kBin : 1];
+    __shared__ unsigned long long tile[MODE == kRasterShadow ? 1 : kBin * kBin];
+    __shared__ uint32_t tile32[MODE == kRasterShadow ? kBin * kBin : 1];
     __shared__ uint32_t bigq[kRasterThreads];  // record indices of the chunk's large triangles
     __shared__ uint32_t s_nbig;
+    __shared__ unsigned long long s_fmask;  // layers: bit (8*by + bx) set = 8x8 block holds a flagged pixel
     const int b = blockIdx.x, layer = blockIdx.y;
     if (!bin_owned(b, tile_rank, tile_world)) return;
+    if (MODE == kRasterLayers && ls.bin_flag[b] == 0u) return;
     const int bx = b % ws.bins_x, by = b / ws.bins_x;
     const int ox = bx * kBin, oy = by * kBin;
+    if (MODE == kRasterLayers) {
+        if (threadIdx.x == 0) s_fmask = 0ull;
+        __syncthreads();
+    }
     for (int i = threadIdx.x; i < kBin * kBin; i += kRasterThreads) {
-        if (SHADOW) tile32[i] = 0x3F800000u;
-        else tile[i] = 0x3F800000FFFFFFFFull;
+        if (MODE == kRasterShadow) tile32[i] = 0x3F800000u;
+        else if (MODE == kRasterColor) tile[i] = 0x3F800000FFFFFFFFull;
+        else {
+            // a wavefront holds one 64-pixel row of the bin
+            int px = ox + (i & (kBin - 1)), py = oy + (i / kBin);
+            uint32_t slot = (px < W && py < H) ? ls.rp_slot[(size_t)py * W + px] : 0u;
+            tile[i] = (unsigned long long)slot;
+            unsigned long long m = __ballot(slot != 0u);
+            m |= m >> 4; m |= m >> 2; m |= m >> 1;
+            m &= 0x0101010101010101ull;
+            const unsigned long long bits = (m * 0x0102040810204080ull) >> 56;  // one bit per 8 pixels
+            if ((threadIdx.x & 63) == 0 && bits) atomicOr(&s_fmask, bits << (8 * ((i / kBin) >> 3)));
+        }
     }
     const uint32_t gb = (uint32_t)layer * (uint32_t)(ws.bins_x * ws.bins_y) + (uint32_t)b;
     const uint32_t n = ws.bin_count[gb], off = ws.bin_offset[gb];
@@ -442,7 +486,20 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
             int y0 = imax((int)(r.bbmin >> 16), oy), y1 = imin((int)(r.bbmax >> 16), oy + kBin - 1);
             const int fw = imax(r.X0, imax(r.X1, r.X2)) - imin(r.X0, imin(r.X1, r.X2));
             const int fh = imax(r.Y0, imax(r.Y1, r.Y2)) - imin(r.Y0, imin(r.Y1, r.Y2));
-            if (fw <= 64 * 256 && fh <= 64 * 256 && (x1 - x0 + 1) * (y1 - y0 + 1) <= WR_RASTER_LANE_AREA) {
+            bool wanted = true;
+            if (MODE == kRasterLayers) {
+                // 8x8 blocks of the bin the triangle's box touches, against the flagged blocks
+                wanted = false;
+                if (x0 <= x1 && y0 <= y1) {
+                    const int c0b = (x0 - ox) >> 3, c1b = (x1 - ox) >> 3, r0b = (y0 - oy) >> 3, r1b = (y1 - oy) >> 3;
+                    const unsigned long long cols = ((1ull << (c1b - c0b + 1)) - 1ull) << c0b;
+                    const int nrow = 8 * (r1b - r0b + 1);
+                    const unsigned long long rows = (nrow >= 64 ? ~0ull : ((1ull << nrow) - 1ull)) << (8 * r0b);
+                    wanted = ((cols * 0x0101010101010101ull) & rows & s_fmask) != 0ull;
+                }
+            }
+            if (!wanted) {
+            } else if (fw <= 64 * 256 && fh <= 64 * 256 && (x1 - x0 + 1) * (y1 - y0 + 1) <= WR_RASTER_LANE_AREA) {
                 // The triangle's vertices span at most 64x64 pixels, so every edge function
                 // stays below 2^30 over its box and can be stepped in 32-bit integers; the
                 // values are the same integers the 64-bit evaluation gives.
@@ -460,13 +517,7 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
                             float l1 = (float)(b1 - e.tlb[1]) * r.inv2A, l2 = (float)(b2 - e.tlb[2]) * r.inv2A;
                             float z = (r.z0 + l1 * r.dz1) + l2 * r.dz2;
                             z = fminf(fmaxf(z, 0.0f), 1.0f);
-                            int li = (py - oy) * kBin + (px - ox);
-                            if (SHADOW) {
-                                float zb = fminf(fmaxf(z + r.iw0, 0.0f), 1.0f);
-                                atomicMin(&tile32[li], f2u(zb));
-                            } else {
-                                if (z < 1.0f) atomicMin(&tile[li], ((unsigned long long)f2u(z) << 32) | (unsigned long long)r.id);
-                            }
+                            raster_emit<MODE>(r, z, (py - oy) * kBin + (px - ox), tile, tile32, ls);
                         }
                         b0 += dx0; b1 += dx1; b2 += dx2;
                     }
@@ -490,10 +541,11 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
                 for (int qx = x0 >> 3; qx <= (x1 >> 3); ++qx) {
                     int bx0 = imax(qx * 8, x0), bx1 = imin(qx * 8 + 7, x1);
                     int by0 = imax(qy * 8, y0), by1 = imin(qy * 8 + 7, y1);
+                    if (MODE == kRasterLayers && !((s_fmask >> (8 * (qy - (oy >> 3)) + (qx - (ox >> 3)))) & 1ull)) continue;
                     if (box_rejected(e, bx0, by0, bx1, by1)) continue;
                     int px = qx * 8 + lx, py = qy * 8 + ly;
                     if (px < x0 || px > x1 || py < y0 || py > y1) continue;
-                    raster_pixel<SHADOW>(r, e, px, py, ox, oy, tile, tile32);
+                    raster_pixel<MODE>(r, e, px, py, ox, oy, tile, tile32, ls);
                 }
         }
         __syncthreads();
@@ -503,8 +555,11 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
         int px = ox + (i & (kBin - 1)), py = oy + (i / kBin);
         if (px >= W || py >= H) continue;
         size_t o = (size_t)layer * (size_t)W * (size_t)H + (size_t)py * W + px;
-        if (SHADOW) {
+        if (MODE == kRasterShadow) {
             depth[o] = u2f(tile32[i]);
+        } else if (MODE == kRasterLayers) {
+            unsigned long long k = tile[i];
+            if ((uint32_t)k != 0u) ls.list_count[(uint32_t)k - 1u] = (uint32_t)(k >> 32);
         } else {
             unsigned long long k = tile[i];
             vis[o] = (uint32_t)k;
@@ -514,6 +569,23 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
 }
 
 // ------------------------------------------------------------------ deferred shading
+// Work space of the ordered-blend kernels (k_shade flags, k_raster<kRasterLayers> collects,
+// k_resolve orders, k_shade_frags shades, k_blend blends).
+struct BlendWS {
+    uint32_t* rp_slot;     // [H][W] list slot + 1 of a flagged pixel, else 0
+    uint32_t* slot_pixel;  // [cap] pixel index of a slot
+    uint32_t* counts;      // [0] flagged pixels, [1] fragments to shade, [2] slow pixels; cleared every frame
+    uint32_t* bin_flag;    // [bins] bin holds a flagged pixel; cleared every frame
+    uint2* lists;          // [cap][kReplayK] (id, depth bits) of the fragments covering a flagged pixel
+    uint32_t* list_count;  // [cap]
+    uint32_t* slow_slots;  // [cap] slots left to k_replay_slow
+    uint2* slot_frags;     // [cap] first fragment item, number of items (kSlotDone: colour already final)
+    uint2* frag_item;      // [frag_cap] (slot, id), a pixel's items adjacent and in draw order
+    float4* frag_src;      // [frag_cap] shaded fragment colour
+    uint32_t cap, frag_cap;
+};
+constexpr uint32_t kSlotDone = 0xFFFFFFFFu;
+
 struct ShadeArgs {
     FrameConsts fc;
     RasterWS ws;
@@ -530,7 +602,7 @@ struct ShadeArgs {
     const float* tables;
     const float* shadow;
     unsigned long long* counters;  // [0] fog fragments [1] noise evals [2] shaded fragments [3] replay pixels [4] slow-path pixels
-    uint8_t* rp_flag;              // [H][W] 1 where the pixel needs ordered blending
+    BlendWS bw;
 };
 
 // Interpolates the VertexOutput of one fragment and runs pbr.wgsl's fs_main on it.
@@ -631,8 +703,6 @@ __device__ __attribute__((noinline)) uint32_t replay_pixel(const ShadeArgs& a, i
     return col;
 }
 
-constexpr int kReplayK = 16;  // covering fragments kept per pixel before the slow path
-
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
     // 16x16 pixels per workgroup, each wavefront an 8x8 block
@@ -645,7 +715,7 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
     const size_t pi = (size_t)py * a.fc.W + px;
     const uint32_t id = a.vis[pi];
     ColorTables ct{a.tables};
-    a.rp_flag[pi] = 0;
+    a.bw.rp_slot[pi] = 0;
     if (id == kVisNone) { a.color[pi] = 0xFF000000u; return; }  // clear colour (0,0,0,1), state.rs:696-701
     const uint32_t tri = id >> 3;
     if (tri >= a.ntris_geom) {  // light marker, light_debug.wgsl:23-26
@@ -669,138 +739,147 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
 #if defined(WR_ABLATE) && (WR_ABLATE & 1)
         a.color[pi] = blend_pack(ct, 0xFF000000u, src, true);
 #else
-        a.rp_flag[pi] = 1;
+        // one slot per flagged pixel, allocated with one atomic per wavefront
+        const unsigned long long m = __ballot(1);
+        const int leader = (int)__builtin_ctzll(m);
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&a.bw.counts[0], (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, leader);
+        const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        a.bw.rp_slot[pi] = slot + 1u;
+        a.bw.slot_pixel[slot] = (uint32_t)pi;
+        a.bw.bin_flag[bin] = 1u;
 #endif
     }
 }
 
-// Compact per-triangle data for the ordered-blend kernel, staged in LDS.
-struct ReplayRec {
-    int32_t A[3], B[3];
-    int32_t tlb;      // bit i set: edge i is not top-left
-    uint32_t id;
-    int64_t C[3];
-    float z0, dz1, dz2, inv2A;
-    uint32_t bbmin, bbmax;
-};
-static_assert(sizeof(ReplayRec) == 80, "ReplayRec layout");
-
-// Ordered blending for the pixels k_shade flagged; one workgroup per 16x16 pixel block, one
-// thread per pixel.  Pass 1 walks the triangle list of the block's bin in chunks of 256:
-// every thread fetches one record, records whose bounding box misses the block are
-// dropped, the rest are compacted into LDS, and then all lanes test the same staged record
-// at once against their own pixel, collecting the fragments that cover it.  Sorted by
-// triangle id these give the draw order, and a running minimum over depth gives the
-// fragments that passed the depth test when drawn.  Pass 2 shades and blends those,
-// starting at the last one whose material cannot be translucent (it replaced everything
-// under it).  Pixels covered by more than kReplayK fragments take replay_pixel.
-template <bool COUNT>
-__global__ __launch_bounds__(256) void k_replay(ShadeArgs a) {
-    __shared__ ReplayRec srec[256];
+// Ordered blending, step 2 (step 1 is k_raster<kRasterLayers>): one thread per flagged
+// pixel.  Sorted by triangle id the collected fragments give the draw order, and a running
+// minimum over depth gives those that passed the depth test when drawn.  The ones from the
+// last fragment whose material cannot be translucent onwards (it replaced everything under
+// it) become items for k_shade_frags.  Pixels covered by more than kReplayK fragments, or
+// left without room in the item buffer, are queued for k_replay_slow.
+__global__ __launch_bounds__(256) void k_resolve(ShadeArgs a) {
     __shared__ uint32_t cid[kReplayK][256];
     __shared__ float cz[kReplayK][256];
-    __shared__ uint32_t s_m;
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int bx0 = blockIdx.x * 16, by0 = blockIdx.y * 16;
-    const int px = bx0 + (wave & 1) * 8 + (lane & 7);
-    const int py = by0 + (wave >> 1) * 8 + (lane >> 3);
-    const RasterWS& ws = a.ws;
-    const int bin = (by0 / kBin) * ws.bins_x + (bx0 / kBin);
-    if (a.fc.tile_world > 1 && (bin % a.fc.tile_world) != a.fc.tile_rank) return;
-    const bool inside = px < a.fc.W && py < a.fc.H;
-    const size_t pi = (size_t)py * a.fc.W + px;
-    const bool active = inside && a.rp_flag[pi] != 0;
-    if (!__syncthreads_or(active ? 1 : 0)) return;
-    const int bx1 = imin(bx0 + 15, a.fc.W - 1), by1 = imin(by0 + 15, a.fc.H - 1);
-    const uint32_t n = ws.bin_count[bin], off = ws.bin_offset[bin];
-    ColorTables ct{a.tables};
-    const int32_t sx = px * 256 + 128, sy = py * 256 + 128;
-    int cnt = 0;
-    for (uint32_t c0 = 0; c0 < n; c0 += 256) {
-        if (tid == 0) s_m = 0;
-        __syncthreads();
-        if (c0 + tid < n && off + c0 + tid < ws.items_cap) {
-            const Rec* rp = &ws.recs[ws.bin_items[off + c0 + tid]];
-            uint32_t bbmin = rp->bbmin, bbmax = rp->bbmax;
-            if (!((int)(bbmin & 0xffffu) > bx1 || (int)(bbmax & 0xffffu) < bx0 || (int)(bbmin >> 16) > by1 || (int)(bbmax >> 16) < by0)) {
-                Rec r = load_rec(rp);
-                Edges e;
-                make_edges(r, e);
-                if (!box_rejected(e, bx0, by0, bx1, by1)) {
-                    ReplayRec& s = srec[atomicAdd(&s_m, 1u)];
-                    for (int i = 0; i < 3; ++i) { s.A[i] = e.A[i]; s.B[i] = e.B[i]; s.C[i] = e.C[i]; }
-                    s.tlb = (e.tlb[0] & 1) | (e.tlb[1] & 2) | (e.tlb[2] & 4);
-                    s.id = r.id; s.z0 = r.z0; s.dz1 = r.dz1; s.dz2 = r.dz2; s.inv2A = r.inv2A;
-                    s.bbmin = r.bbmin; s.bbmax = r.bbmax;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const BlendWS& bw = a.bw;
+    const uint32_t nslots = min(bw.counts[0], bw.cap);
+    for (uint32_t s0 = blockIdx.x * 256u; s0 < nslots; s0 += gridDim.x * 256u) {
+        const uint32_t s = s0 + (uint32_t)tid;
+        const bool live = s < nslots;
+        const uint32_t cnt = live ? bw.list_count[s] : 0u;
+        bool slow = cnt > (uint32_t)kReplayK;
+        int np = 0, start = 0;
+        if (live && !slow) {
+            // the whole list in flight at once, then insertion by ascending id = draw order
+            const uint4* row = reinterpret_cast<const uint4*>(bw.lists + (size_t)s * kReplayK);
+            uint4 q[kReplayK / 2];
+#pragma unroll
+            for (int i = 0; i < kReplayK / 2; ++i) q[i] = (uint32_t)(2 * i) < cnt ? row[i] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int i = 0; i < kReplayK; ++i) {
+                if ((uint32_t)i < cnt) {
+                    const uint32_t id = (i & 1) ? q[i >> 1].z : q[i >> 1].x;
+                    const float z = u2f((i & 1) ? q[i >> 1].w : q[i >> 1].y);
+                    int j = i - 1;
+                    while (j >= 0 && cid[j][tid] > id) { cid[j + 1][tid] = cid[j][tid]; cz[j + 1][tid] = cz[j][tid]; --j; }
+                    cid[j + 1][tid] = id; cz[j + 1][tid] = z;
                 }
             }
-        }
-        __syncthreads();
-        const int m = (int)s_m;
-        if (active) {
-            for (int j = 0; j < m; ++j) {
-                const ReplayRec& s = srec[j];
-                if (px < (int)(s.bbmin & 0xffffu) || px > (int)(s.bbmax & 0xffffu) || py < (int)(s.bbmin >> 16) || py > (int)(s.bbmax >> 16)) continue;
-                int64_t E0 = (int64_t)s.A[0] * sx + (int64_t)s.B[0] * sy + s.C[0];
-                int64_t E1 = (int64_t)s.A[1] * sx + (int64_t)s.B[1] * sy + s.C[1];
-                int64_t E2 = (int64_t)s.A[2] * sx + (int64_t)s.B[2] * sy + s.C[2];
-                if (((E0 - (s.tlb & 1)) | (E1 - ((s.tlb >> 1) & 1)) | (E2 - ((s.tlb >> 2) & 1))) < 0) continue;
-                float l1 = (float)E1 * s.inv2A, l2 = (float)E2 * s.inv2A;
-                float z = (s.z0 + l1 * s.dz1) + l2 * s.dz2;
-                z = fminf(fmaxf(z, 0.0f), 1.0f);
-                if (cnt < kReplayK) { cid[cnt][tid] = s.id; cz[cnt][tid] = z; }
-                ++cnt;
+            float d = 1.0f;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                float z = cz[i][tid];
+                if (z < d) {
+                    d = z;
+                    cid[np][tid] = cid[i][tid];
+                    ++np;
+                }
             }
+            for (start = np - 1; start > 0; --start) {
+                uint32_t tri = cid[start][tid] >> 3;
+                if (tri >= a.ntris_geom || a.mats[a.tri_mat[tri]].opaque) break;
+            }
+            if (start < 0) start = 0;
         }
-        __syncthreads();
-    }
-    if (!active) return;  // no barrier below this point
-    if (cnt > kReplayK) {
-        if (COUNT) atomicAdd(&a.counters[4], 1ull);
-        a.color[pi] = replay_pixel(a, px, py);
-        return;
-    }
-    // draw order = ascending id (insertion sort; cnt is small)
-    for (int i = 1; i < cnt; ++i) {
-        uint32_t ki = cid[i][tid];
-        float zi = cz[i][tid];
-        int j = i - 1;
-        while (j >= 0 && cid[j][tid] > ki) { cid[j + 1][tid] = cid[j][tid]; cz[j + 1][tid] = cz[j][tid]; --j; }
-        cid[j + 1][tid] = ki; cz[j + 1][tid] = zi;
-    }
-    // fragments that passed depth test Less at draw time, compacted in place
-    int np = 0, start = 0;
-    float d = 1.0f;
-    for (int i = 0; i < cnt; ++i) {
-        float z = cz[i][tid];
-        if (z < d) {
-            d = z;
-            uint32_t id = cid[i][tid];
-            uint32_t tri = id >> 3;
-            if (tri >= a.ntris_geom || a.mats[a.tri_mat[tri]].opaque) start = np;
-            cid[np][tid] = id;
-            ++np;
+        // room in the item buffer: exclusive prefix sum over the wavefront, one atomic
+        const uint32_t want = (live && !slow) ? (uint32_t)(np - start) : 0u;
+        uint32_t incl = want;
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t v = (uint32_t)__shfl_up((int)incl, d);
+            if (lane >= d) incl += v;
         }
-    }
-    uint32_t col = 0xFF000000u;
-    for (int k = start; k < np; ++k) {
-        uint32_t id = cid[k][tid];
-        uint32_t tri = id >> 3;
-        if (tri >= a.ntris_geom) {
-            col = blend_pack(ct, col, V4{a.fc.light_color[0], a.fc.light_color[1], a.fc.light_color[2], 1.0f}, false);
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+        uint32_t base = 0;
+        if (lane == 0 && total) base = atomicAdd(&bw.counts[1], total);
+        base = (uint32_t)__shfl((int)base, 0);
+        if ((unsigned long long)base + total > bw.frag_cap) slow = true;
+        if (!live) continue;
+        if (slow) {
+            bw.slow_slots[atomicAdd(&bw.counts[2], 1u)] = s;
+            bw.slot_frags[s] = make_uint2(0u, kSlotDone);
             continue;
         }
-        const float* beta;
-        Rec r = fetch_rec(ws, id, beta);
-        Edges e;
-        make_edges(r, e);
-        int64_t E[3];
-        edge_eval(e, px, py, E);
-        V4 src = shade_fragment(a, r, beta, e, tri, px, py, E);
-        col = blend_pack(ct, col, src, true);
+        const uint32_t first = base + incl - want;
+        for (uint32_t k = 0; k < want; ++k) bw.frag_item[first + k] = make_uint2(s, cid[start + (int)k][tid]);
+        bw.slot_frags[s] = make_uint2(first, want);
     }
-    a.color[pi] = col;
+}
+
+// Ordered blending of the pixels k_resolve queued: the general, slow method.
+template <bool COUNT>
+__global__ __launch_bounds__(64) void k_replay_slow(ShadeArgs a) {
+    const BlendWS& bw = a.bw;
+    const uint32_t n = min(bw.counts[2], bw.cap);
+    for (uint32_t k = blockIdx.x * 64u + threadIdx.x; k < n; k += gridDim.x * 64u) {
+        const uint32_t pi = bw.slot_pixel[bw.slow_slots[k]];
+        if (COUNT) atomicAdd(&a.counters[4], 1ull);
+        a.color[pi] = replay_pixel(a, (int)(pi % (uint32_t)a.fc.W), (int)(pi / (uint32_t)a.fc.W));
+    }
+}
+
+// Ordered blending, step 3: one thread per fragment item runs pbr.wgsl's fs_main (the light
+// marker, drawn with REPLACE, has a constant colour: light_debug.wgsl:23-26).
+__global__ __launch_bounds__(64) void k_shade_frags(ShadeArgs a) {
+    const BlendWS& bw = a.bw;
+    const uint32_t n = min(bw.counts[1], bw.frag_cap);
+    for (uint32_t f = blockIdx.x * 64u + threadIdx.x; f < n; f += gridDim.x * 64u) {
+        const uint2 it = bw.frag_item[f];
+        const uint32_t pi = bw.slot_pixel[it.x];
+        const int px = (int)(pi % (uint32_t)a.fc.W), py = (int)(pi / (uint32_t)a.fc.W);
+        const uint32_t tri = it.y >> 3;
+        V4 src = V4{a.fc.light_color[0], a.fc.light_color[1], a.fc.light_color[2], 1.0f};
+        if (tri < a.ntris_geom) {
+            const float* beta;
+            Rec r = fetch_rec(a.ws, it.y, beta);
+            Edges e;
+            make_edges(r, e);
+            int64_t E[3];
+            edge_eval(e, px, py, E);
+            src = shade_fragment(a, r, beta, e, tri, px, py, E);
+        }
+        bw.frag_src[f] = make_float4(src.x, src.y, src.z, src.w);
+    }
+}
+
+// Ordered blending, step 4: blends a pixel's shaded fragments over the clear colour in draw
+// order (geometry: SrcAlpha/OneMinusSrcAlpha, state.rs:465-467; light marker: REPLACE,
+// state.rs:480-482).
+__global__ __launch_bounds__(256) void k_blend(ShadeArgs a) {
+    const BlendWS& bw = a.bw;
+    ColorTables ct{a.tables};
+    const uint32_t nslots = min(bw.counts[0], bw.cap);
+    for (uint32_t s = blockIdx.x * 256u + threadIdx.x; s < nslots; s += gridDim.x * 256u) {
+        const uint2 fr = bw.slot_frags[s];
+        if (fr.y == kSlotDone) continue;
+        uint32_t col = 0xFF000000u;
+        for (uint32_t k = 0; k < fr.y; ++k) {
+            const float4 c = bw.frag_src[fr.x + k];
+            const bool geometry = (bw.frag_item[fr.x + k].y >> 3) < a.ntris_geom;
+            col = blend_pack(ct, col, V4{c.x, c.y, c.z, c.w}, geometry);
+        }
+        a.color[bw.slot_pixel[s]] = col;
+    }
 }
 
 // ------------------------------------------------------------------ fog
