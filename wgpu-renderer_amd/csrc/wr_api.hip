@@ -475,11 +475,12 @@ int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do
         if (max_entries)
             hipLaunchKernelGGL(k_fog_tables, dim3((max_entries + 255u) / 256u, 16, 1), dim3(256), 0, ctx->stream, fa.tables_noise);
         dim3 mg((uint32_t)(((size_t)ctx->W * ctx->H + 63) / 64), 1, 1);
+        dim3 fg((uint32_t)(ctx->W + kFogBlock - 1) / kFogBlock, (uint32_t)(ctx->H + kFogBlock - 1) / kFogBlock, 1);
         if (ctx->counting) {
-            hipLaunchKernelGGL(k_fog_setup<true>, pg, dim3(256), 0, ctx->stream, fa);
+            hipLaunchKernelGGL(k_fog_setup<true>, fg, dim3(1024), 0, ctx->stream, fa);
             hipLaunchKernelGGL(k_fog_march<true>, mg, dim3(64), 0, ctx->stream, fa);
         } else {
-            hipLaunchKernelGGL(k_fog_setup<false>, pg, dim3(256), 0, ctx->stream, fa);
+            hipLaunchKernelGGL(k_fog_setup<false>, fg, dim3(1024), 0, ctx->stream, fa);
             hipLaunchKernelGGL(k_fog_march<false>, mg, dim3(64), 0, ctx->stream, fa);
         }
     }

@@ -126,6 +126,30 @@ __device__ inline uint32_t wave_agg_inc(uint32_t* counters, bool active, uint32_
     return pos;
 }
 
+// Appends `want` entries per thread to a global list: returns the index of the thread's first
+// entry.  One global atomic per workgroup (atomics of a whole grid on one address are
+// serialised at the memory side and cost far more than anything else these kernels do), an
+// LDS atomic per wavefront.  s_cnt / s_base are two LDS words of the caller; every thread of
+// the workgroup must call this (two barriers inside).
+__device__ inline uint32_t group_append(uint32_t* counter, uint32_t want, uint32_t* s_cnt, uint32_t* s_base) {
+    const int lane = (int)(threadIdx.x & 63u);
+    if (threadIdx.x == 0) *s_cnt = 0u;
+    __syncthreads();
+    uint32_t incl = want;
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t v = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += v;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    uint32_t wbase = 0;
+    if (lane == 0 && total) wbase = atomicAdd(s_cnt, total);
+    wbase = (uint32_t)__shfl((int)wbase, 0);
+    __syncthreads();
+    if (threadIdx.x == 0) *s_base = *s_cnt ? atomicAdd(counter, *s_cnt) : 0u;
+    __syncthreads();
+    return *s_base + wbase + incl - want;
+}
+
 __device__ inline bool bin_owned(int b, int tile_rank, int tile_world) {
     return tile_world <= 1 || (b % tile_world) == tile_rank;
 }
@@ -705,52 +729,53 @@ __device__ __attribute__((noinline)) uint32_t replay_pixel(const ShadeArgs& a, i
 
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
+    __shared__ uint32_t s_cnt, s_base;
     // 16x16 pixels per workgroup, each wavefront an 8x8 block
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
     const int py = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    if (px >= a.fc.W || py >= a.fc.H) return;
-    const int bin = (py / kBin) * a.ws.bins_x + (px / kBin);
+    const int bin = (py / kBin) * a.ws.bins_x + (px / kBin);  // the same for the whole workgroup
     if (a.fc.tile_world > 1 && (bin % a.fc.tile_world) != a.fc.tile_rank) return;
+    const bool live = px < a.fc.W && py < a.fc.H;
     const size_t pi = (size_t)py * a.fc.W + px;
-    const uint32_t id = a.vis[pi];
+    const uint32_t id = live ? a.vis[pi] : kVisNone;
     ColorTables ct{a.tables};
-    a.bw.rp_slot[pi] = 0;
-    if (id == kVisNone) { a.color[pi] = 0xFF000000u; return; }  // clear colour (0,0,0,1), state.rs:696-701
-    const uint32_t tri = id >> 3;
-    if (tri >= a.ntris_geom) {  // light marker, light_debug.wgsl:23-26
+    bool flagged = false;
+    if (id == kVisNone) {
+        if (live) a.color[pi] = 0xFF000000u;  // clear colour (0,0,0,1), state.rs:696-701
+    } else if ((id >> 3) >= a.ntris_geom) {  // light marker, light_debug.wgsl:23-26
         a.color[pi] = blend_pack(ct, 0u, V4{a.fc.light_color[0], a.fc.light_color[1], a.fc.light_color[2], 1.0f}, false);
+    } else {
+        const uint32_t tri = id >> 3;
+        const float* beta;
+        Rec r = fetch_rec(a.ws, id, beta);
+        Edges e;
+        make_edges(r, e);
+        int64_t E[3];
+        edge_eval(e, px, py, E);
+        V4 src = shade_fragment(a, r, beta, e, tri, px, py, E);
+        if (COUNT) atomicAdd(&a.counters[2], 1ull);
+        if (src.w == 1.0f) {
+            a.color[pi] = blend_pack(ct, 0u, src, false);  // alpha 1 replaces whatever was blended before
+        } else {
+            // the front-most fragment is not opaque: this pixel's colour depends on draw order;
+            // flag it for the ordered-blend kernels
+            if (COUNT) atomicAdd(&a.counters[3], 1ull);
+#if defined(WR_ABLATE) && (WR_ABLATE & 1)
+            a.color[pi] = blend_pack(ct, 0xFF000000u, src, true);
+#else
+            flagged = true;
+#endif
+        }
+    }
+    if (!__syncthreads_or(flagged ? 1 : 0)) {
+        if (live) a.bw.rp_slot[pi] = 0u;
         return;
     }
-    const float* beta;
-    Rec r = fetch_rec(a.ws, id, beta);
-    Edges e;
-    make_edges(r, e);
-    int64_t E[3];
-    edge_eval(e, px, py, E);
-    V4 src = shade_fragment(a, r, beta, e, tri, px, py, E);
-    if (COUNT) atomicAdd(&a.counters[2], 1ull);
-    if (src.w == 1.0f) {
-        a.color[pi] = blend_pack(ct, 0u, src, false);  // alpha 1 replaces whatever was blended before
-    } else {
-        // the front-most fragment is not opaque: this pixel's colour depends on draw order;
-        // flag it for the ordered-blend kernel
-        if (COUNT) atomicAdd(&a.counters[3], 1ull);
-#if defined(WR_ABLATE) && (WR_ABLATE & 1)
-        a.color[pi] = blend_pack(ct, 0xFF000000u, src, true);
-#else
-        // one slot per flagged pixel, allocated with one atomic per wavefront
-        const unsigned long long m = __ballot(1);
-        const int leader = (int)__builtin_ctzll(m);
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&a.bw.counts[0], (uint32_t)__popcll(m));
-        base = (uint32_t)__shfl((int)base, leader);
-        const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        a.bw.rp_slot[pi] = slot + 1u;
-        a.bw.slot_pixel[slot] = (uint32_t)pi;
-        a.bw.bin_flag[bin] = 1u;
-#endif
-    }
+    const uint32_t slot = group_append(&a.bw.counts[0], flagged ? 1u : 0u, &s_cnt, &s_base);
+    if (live) a.bw.rp_slot[pi] = flagged ? slot + 1u : 0u;
+    if (flagged) a.bw.slot_pixel[slot] = (uint32_t)pi;
+    if (threadIdx.x == 0) a.bw.bin_flag[bin] = 1u;
 }
 
 // Ordered blending, step 2 (step 1 is k_raster<kRasterLayers>): one thread per flagged
@@ -762,7 +787,8 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
 __global__ __launch_bounds__(256) void k_resolve(ShadeArgs a) {
     __shared__ uint32_t cid[kReplayK][256];
     __shared__ float cz[kReplayK][256];
-    const int tid = threadIdx.x, lane = tid & 63;
+    __shared__ uint32_t s_cnt, s_base;
+    const int tid = threadIdx.x;
     const BlendWS& bw = a.bw;
     const uint32_t nslots = min(bw.counts[0], bw.cap);
     for (uint32_t s0 = blockIdx.x * 256u; s0 < nslots; s0 += gridDim.x * 256u) {
@@ -802,25 +828,18 @@ __global__ __launch_bounds__(256) void k_resolve(ShadeArgs a) {
             }
             if (start < 0) start = 0;
         }
-        // room in the item buffer: exclusive prefix sum over the wavefront, one atomic
+        // room in the item buffer
         const uint32_t want = (live && !slow) ? (uint32_t)(np - start) : 0u;
-        uint32_t incl = want;
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t v = (uint32_t)__shfl_up((int)incl, d);
-            if (lane >= d) incl += v;
-        }
-        const uint32_t total = (uint32_t)__shfl((int)incl, 63);
-        uint32_t base = 0;
-        if (lane == 0 && total) base = atomicAdd(&bw.counts[1], total);
-        base = (uint32_t)__shfl((int)base, 0);
-        if ((unsigned long long)base + total > bw.frag_cap) slow = true;
+        const uint32_t first = group_append(&bw.counts[1], want, &s_cnt, &s_base);
+        if ((unsigned long long)first + want > bw.frag_cap) slow = true;
         if (!live) continue;
         if (slow) {
+            // items it was given but cannot use are marked, so that k_shade_frags skips them
+            for (uint32_t k = 0; k < want && first + k < bw.frag_cap; ++k) bw.frag_item[first + k] = make_uint2(kSlotDone, 0u);
             bw.slow_slots[atomicAdd(&bw.counts[2], 1u)] = s;
             bw.slot_frags[s] = make_uint2(0u, kSlotDone);
             continue;
         }
-        const uint32_t first = base + incl - want;
         for (uint32_t k = 0; k < want; ++k) bw.frag_item[first + k] = make_uint2(s, cid[start + (int)k][tid]);
         bw.slot_frags[s] = make_uint2(first, want);
     }
@@ -845,6 +864,7 @@ __global__ __launch_bounds__(64) void k_shade_frags(ShadeArgs a) {
     const uint32_t n = min(bw.counts[1], bw.frag_cap);
     for (uint32_t f = blockIdx.x * 64u + threadIdx.x; f < n; f += gridDim.x * 64u) {
         const uint2 it = bw.frag_item[f];
+        if (it.x == kSlotDone) continue;
         const uint32_t pi = bw.slot_pixel[it.x];
         const int px = (int)(pi % (uint32_t)a.fc.W), py = (int)(pi / (uint32_t)a.fc.W);
         const uint32_t tri = it.y >> 3;
@@ -923,42 +943,104 @@ __device__ inline bool fog_fragment(const FogArgs& a, const Rec& r, const float*
     return true;
 }
 
-// Fog pass, part 1 (state.rs:763-804): rasterises the fog volume per pixel.  A pixel with
-// exactly one fog fragment (always the case for a convex volume) whose march is not
-// empty becomes a work item for k_fog_march, appended with one atomic per wavefront; a
-// pixel with several fragments is finished here, in draw order.
+// Edge functions and depth plane of one record, staged in LDS for a 16x16 pixel block.
+struct StagedRec {
+    int32_t A[3], B[3];
+    int32_t tlb;      // bit i set: edge i is not top-left
+    uint32_t ri;      // record index
+    int64_t C[3];
+    float z0, dz1, dz2, inv2A;
+    uint32_t bbmin, bbmax;
+    uint32_t id, pad;
+};
+static_assert(sizeof(StagedRec) == 88, "StagedRec layout");
+
+// Fog pass, part 1 (state.rs:763-804): rasterises the fog volume per pixel.  A workgroup
+// owns a 32x32 pixel block: its threads first fetch the volume's records, one each, and
+// stage those that can touch the block in LDS (edge set-up done once per record, not once
+// per pixel); then every pixel tests the staged records.  A pixel with exactly one fog
+// fragment (always the case for a convex volume) whose march is not empty becomes a work
+// item for k_fog_march, appended with one atomic per workgroup; a pixel with several
+// fragments is finished here, in draw order.
+constexpr int kFogBlock = 32;
 template <bool COUNT>
-__global__ __launch_bounds__(256) void k_fog_setup(FogArgs a) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int py = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    bool live = px < a.fc.W && py < a.fc.H;
-    if (live && a.fc.tile_world > 1) {
-        int b = (py / kBin) * ((a.fc.W + kBin - 1) / kBin) + (px / kBin);
-        live = (b % a.fc.tile_world) == a.fc.tile_rank;
+__global__ __launch_bounds__(1024) void k_fog_setup(FogArgs a) {
+    __shared__ StagedRec srec[256];
+    __shared__ uint32_t s_m, s_cnt, s_base;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int bx0 = blockIdx.x * kFogBlock, by0 = blockIdx.y * kFogBlock;
+    const int px = bx0 + (wave & 3) * 8 + (lane & 7);
+    const int py = by0 + (wave >> 2) * 8 + (lane >> 3);
+    if (a.fc.tile_world > 1) {  // a block lies in one bin
+        int b = (by0 / kBin) * ((a.fc.W + kBin - 1) / kBin) + (bx0 / kBin);
+        if ((b % a.fc.tile_world) != a.fc.tile_rank) return;
     }
+    const bool live = px < a.fc.W && py < a.fc.H;
+    const int bx1 = imin(bx0 + kFogBlock - 1, a.fc.W - 1), by1 = imin(by0 + kFogBlock - 1, a.fc.H - 1);
     const size_t pi = (size_t)py * a.fc.W + px;
     const float zbuf = live ? a.depth[pi] : 0.0f;
+    const int32_t sx = px * 256 + 128, sy = py * 256 + 128;
+    const uint32_t nrec = a.ws.slots + min(a.ws.ovf_count[0], a.ws.ovf_cap);
     int nfrag = 0;
-    V3 origin = v3(0.0f, 0.0f, 0.0f);
-    float max_depth = 0.0f;
-    if (live) {
-        for (uint32_t t = 0; t < a.ntris && nfrag < 2; ++t) {
-            Rec slot = load_rec(&a.ws.recs[t]);
-            if (slot.id == kRecInvalid) continue;
-            uint32_t first = t, count = 1;
-            if (slot.id == kRecClippedParent) { first = (uint32_t)slot.X0; count = (uint32_t)slot.Y0; }
-            for (uint32_t s = 0; s < count; ++s) {
-                uint32_t ri = first + s;
-                Rec r = (slot.id == kRecClippedParent) ? load_rec(&a.ws.recs[ri]) : slot;
-                if (r.id >= kRecClippedParent) continue;
-                if (px < (int)(r.bbmin & 0xffffu) || px > (int)(r.bbmax & 0xffffu) || py < (int)(r.bbmin >> 16) || py > (int)(r.bbmax >> 16)) continue;
-                const float* beta = ri >= a.ws.slots ? a.ws.betas + (size_t)(ri - a.ws.slots) * 9 : nullptr;
-                V3 o;
-                float md;
-                if (fog_fragment(a, r, beta, t, px, py, zbuf, o, md)) { origin = o; max_depth = md; ++nfrag; }
+    uint32_t hit_ri = 0;
+    int64_t hit_E[3] = {0, 0, 0};
+    float hit_z = 0.0f;
+    for (uint32_t c0 = 0; c0 < nrec; c0 += 256) {
+        if (tid == 0) s_m = 0;
+        __syncthreads();
+        if (tid < 256 && c0 + tid < nrec) {
+            const Rec* rp = &a.ws.recs[c0 + tid];
+            const uint32_t id = rp->id, bbmin = rp->bbmin, bbmax = rp->bbmax;
+            if (id < kRecClippedParent &&
+                !((int)(bbmin & 0xffffu) > bx1 || (int)(bbmax & 0xffffu) < bx0 || (int)(bbmin >> 16) > by1 || (int)(bbmax >> 16) < by0)) {
+                Rec r = load_rec(rp);
+                Edges e;
+                make_edges(r, e);
+                if (!box_rejected(e, bx0, by0, bx1, by1)) {
+                    StagedRec& q = srec[atomicAdd(&s_m, 1u)];
+                    for (int i = 0; i < 3; ++i) { q.A[i] = e.A[i]; q.B[i] = e.B[i]; q.C[i] = e.C[i]; }
+                    q.tlb = (e.tlb[0] & 1) | (e.tlb[1] & 2) | (e.tlb[2] & 4);
+                    q.ri = c0 + tid; q.id = r.id; q.z0 = r.z0; q.dz1 = r.dz1; q.dz2 = r.dz2; q.inv2A = r.inv2A;
+                    q.bbmin = r.bbmin; q.bbmax = r.bbmax;
+                }
             }
         }
+        __syncthreads();
+        const int m = (int)s_m;
+        if (live) {
+            for (int j = 0; j < m; ++j) {
+                const StagedRec& q = srec[j];
+                if (px < (int)(q.bbmin & 0xffffu) || px > (int)(q.bbmax & 0xffffu) || py < (int)(q.bbmin >> 16) || py > (int)(q.bbmax >> 16)) continue;
+                int64_t E0 = (int64_t)q.A[0] * sx + (int64_t)q.B[0] * sy + q.C[0];
+                int64_t E1 = (int64_t)q.A[1] * sx + (int64_t)q.B[1] * sy + q.C[1];
+                int64_t E2 = (int64_t)q.A[2] * sx + (int64_t)q.B[2] * sy + q.C[2];
+                if (((E0 - (q.tlb & 1)) | (E1 - ((q.tlb >> 1) & 1)) | (E2 - ((q.tlb >> 2) & 1))) < 0) continue;
+                float l1 = (float)E1 * q.inv2A, l2 = (float)E2 * q.inv2A;
+                float z = (q.z0 + l1 * q.dz1) + l2 * q.dz2;
+                z = fminf(fmaxf(z, 0.0f), 1.0f);
+                if (!(z < zbuf)) continue;  // depth test Less, no depth write (state.rs:497-502)
+                hit_ri = q.ri; hit_E[0] = E0; hit_E[1] = E1; hit_E[2] = E2; hit_z = z;
+                if ((q.id >> 3) < a.ntris) ++nfrag;  // (always true for records written this frame)
+            }
+        }
+        __syncthreads();
+    }
+    V3 origin = v3(0.0f, 0.0f, 0.0f);
+    float max_depth = 0.0f;
+    if (nfrag == 1) {
+        // the pre-march part of fog.wgsl's fs_main on the interpolated world position
+        Rec r = load_rec(&a.ws.recs[hit_ri]);
+        const float* beta = hit_ri >= a.ws.slots ? a.ws.betas + (size_t)(hit_ri - a.ws.slots) * 9 : nullptr;
+        float B[3];
+        bary_at(r, beta, hit_E, B);
+        const uint32_t tri = r.id >> 3;
+        V4 w[3];
+        for (int k = 0; k < 3; ++k) {
+            float4 p = a.pos[a.idx[3 * tri + k]];
+            w[k] = mat4_mul(a.fc.model_fog, V4{p.x, p.y, p.z, 1.0f});
+        }
+        origin = v3(ip(B, w[0].x, w[1].x, w[2].x), ip(B, w[0].y, w[1].y, w[2].y), ip(B, w[0].z, w[1].z, w[2].z));
+        max_depth = fog_max_depth(a.fc, a.depth, hit_z, px, py);
     }
     if (nfrag >= 2) {
         // several fog fragments on one pixel: blend them here, one after the other
@@ -989,13 +1071,9 @@ __global__ __launch_bounds__(256) void k_fog_setup(FogArgs a) {
     }
     if (COUNT && nfrag == 1) atomicAdd(&a.counters[0], 1ull);
     const bool item = nfrag == 1 && max_depth > 0.0f;
-    const unsigned long long mask = __ballot(item);
-    if (mask == 0ull) return;
-    uint32_t base = 0;
-    if (lane == (int)__builtin_ctzll(mask)) base = atomicAdd(a.item_count, (uint32_t)__popcll(mask));
-    base = __shfl(base, (int)__builtin_ctzll(mask));
+    if (!__syncthreads_or(item ? 1 : 0)) return;
+    const uint32_t k = group_append(a.item_count, item ? 1u : 0u, &s_cnt, &s_base);
     if (item) {
-        uint32_t k = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
         a.item_pixel[k] = (uint32_t)pi;
         a.item_ray[k] = make_float4(origin.x, origin.y, origin.z, max_depth);
     }
