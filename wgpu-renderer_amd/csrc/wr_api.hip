@@ -900,3 +900,25 @@ void wr_camera_fly_update(float pose[5], const float in[5], float speed, float s
 }
 
 }  // extern "C"
+
+#ifdef WR_DEV
+// Developer build only: copies binning state of the last frame to the host.
+extern "C" int wr_dev_read(WrContext* ctx, int which, void* dst, size_t bytes) {
+    WsAlloc& w = (which & 1) ? ctx->geom : ctx->shadow;
+    const RasterWS& ws = w.ws;
+    size_t nb = (size_t)ws.bins_x * ws.bins_y * ws.layers;
+    size_t nrec = (size_t)ws.layers * ((size_t)ws.slots + ws.ovf_cap);
+    const void* src = nullptr;
+    size_t have = 0;
+    switch (which >> 1) {
+        case 0: src = ws.bin_count; have = nb * 4; break;
+        case 1: src = ws.bb; have = nrec * 8; break;
+        case 2: src = ws.bin_offset; have = nb * 4; break;
+        case 3: src = ws.bin_items; have = (size_t)ws.items_cap * 4; break;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    if (bytes > have) bytes = have;
+    if (hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int)(have / 4 > 0x7fffffff ? 0x7fffffff : have / 4);
+}
+#endif

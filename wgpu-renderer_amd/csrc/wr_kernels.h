@@ -427,6 +427,29 @@ struct LayerSink {
     uint32_t* list_count;      // [slots] fragments seen (may exceed kReplayK)
 };
 
+// A record every lane of the wavefront holds a copy of, moved to scalar registers: what is
+// computed from it afterwards (edge set-up, block stepping, block rejection) then runs on
+// the scalar unit.
+__device__ inline Rec uniform_rec(const Rec& v) {
+    Rec r;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&v);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(Rec) / 4); ++i) dst[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)src[i]);
+    return r;
+}
+
+__device__ inline int64_t uniform_i64(int64_t v) {
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// Position of pixel (x, y) of a bin in its LDS tile.  The eight rows of an 8x8 pixel block
+// are rotated to different column groups, so that a wavefront working on one block spreads
+// over the LDS banks instead of hitting the same eight.
+__device__ inline int tile_index(int x, int y) { return y * kBin + (x ^ ((y & 7) << 3)); }
+
 // One covered sample.  Colour: depth test Less with depth write, the smallest (depth, id)
 // key wins.  Shadow: min of the biased depth.  Layers: a flagged pixel's tile word holds
 // its list slot + 1 in the low half and the fragments seen so far in the high half.
@@ -444,16 +467,6 @@ __device__ inline void raster_emit(const Rec& r, float z, int li, unsigned long 
         uint32_t c = (uint32_t)(old >> 32);
         if (c < (uint32_t)kReplayK) ls.lists[(size_t)((uint32_t)old - 1u) * kReplayK + c] = make_uint2(r.id, f2u(z));
     }
-}
-
-template <int MODE>
-__device__ inline void raster_pixel(const Rec& r, const Edges& e, int px, int py, int ox, int oy,
-                                    unsigned long long* tile, uint32_t* tile32, const LayerSink& ls) {
-    int64_t E[3];
-    edge_eval(e, px, py, E);
-    if (!edges_inside(e, E)) return;
-    float z = depth_at(r, E);
-    raster_emit<MODE>(r, z, (py - oy) * kBin + (px - ox), tile, tile32, ls);
 }
 
 #ifndef WR_RASTER_LANE_AREA
@@ -487,7 +500,7 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
             // a wavefront holds one 64-pixel row of the bin
             int px = ox + (i & (kBin - 1)), py = oy + (i / kBin);
             uint32_t slot = (px < W && py < H) ? ls.rp_slot[(size_t)py * W + px] : 0u;
-            tile[i] = (unsigned long long)slot;
+            tile[tile_index(i & (kBin - 1), i / kBin)] = (unsigned long long)slot;
             unsigned long long m = __ballot(slot != 0u);
             m |= m >> 4; m |= m >> 2; m |= m >> 1;
             m &= 0x0101010101010101ull;
@@ -541,7 +554,7 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
                             float l1 = (float)(b1 - e.tlb[1]) * r.inv2A, l2 = (float)(b2 - e.tlb[2]) * r.inv2A;
                             float z = (r.z0 + l1 * r.dz1) + l2 * r.dz2;
                             z = fminf(fmaxf(z, 0.0f), 1.0f);
-                            raster_emit<MODE>(r, z, (py - oy) * kBin + (px - ox), tile, tile32, ls);
+                            raster_emit<MODE>(r, z, tile_index(px - ox, py - oy), tile, tile32, ls);
                         }
                         b0 += dx0; b1 += dx1; b2 += dx2;
                     }
@@ -554,23 +567,60 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
         __syncthreads();
         const uint32_t nbig = s_nbig;
         for (uint32_t q = wave; q < nbig; q += kRasterThreads / 64) {
-            // wave-uniform record: scalar loads, edge set-up on the scalar unit
+            // Wave-uniform record: scalar loads, edge set-up on the scalar unit.  An edge
+            // function at pixel (8 qx + lx, 8 qy + ly) is a uniform 64-bit value stepped from
+            // block to block plus a per-lane offset fixed per triangle (fill-rule offset
+            // included), so a block costs three 64-bit adds and a sign test per lane.
             const uint32_t ri = __builtin_amdgcn_readfirstlane(bigq[q]);
-            Rec r = load_rec(&recs[ri]);
+            const Rec r = uniform_rec(load_rec(&recs[ri]));
             Edges e;
             make_edges(r, e);
-            int x0 = imax((int)(r.bbmin & 0xffffu), ox), x1 = imin((int)(r.bbmax & 0xffffu), ox + kBin - 1);
-            int y0 = imax((int)(r.bbmin >> 16), oy), y1 = imin((int)(r.bbmax >> 16), oy + kBin - 1);
-            for (int qy = y0 >> 3; qy <= (y1 >> 3); ++qy)
-                for (int qx = x0 >> 3; qx <= (x1 >> 3); ++qx) {
-                    int bx0 = imax(qx * 8, x0), bx1 = imin(qx * 8 + 7, x1);
-                    int by0 = imax(qy * 8, y0), by1 = imin(qy * 8 + 7, y1);
-                    if (MODE == kRasterLayers && !((s_fmask >> (8 * (qy - (oy >> 3)) + (qx - (ox >> 3)))) & 1ull)) continue;
-                    if (box_rejected(e, bx0, by0, bx1, by1)) continue;
-                    int px = qx * 8 + lx, py = qy * 8 + ly;
-                    if (px < x0 || px > x1 || py < y0 || py > y1) continue;
-                    raster_pixel<MODE>(r, e, px, py, ox, oy, tile, tile32, ls);
+            const int x0 = imax((int)(r.bbmin & 0xffffu), ox), x1 = imin((int)(r.bbmax & 0xffffu), ox + kBin - 1);
+            const int y0 = imax((int)(r.bbmin >> 16), oy), y1 = imin((int)(r.bbmax >> 16), oy + kBin - 1);
+            const int qx0 = x0 >> 3, qx1 = x1 >> 3, qy0 = y0 >> 3, qy1 = y1 >> 3;
+            int64_t L[3], Er[3], stepx[3], stepy[3], maxoff[3];
+            edge_eval(e, qx0 * 8, qy0 * 8, Er);
+            for (int i = 0; i < 3; ++i) {
+                L[i] = (int64_t)e.A[i] * (256 * lx) + (int64_t)e.B[i] * (256 * ly) + e.tlb[i];
+                stepx[i] = (int64_t)e.A[i] * 2048;
+                stepy[i] = (int64_t)e.B[i] * 2048;
+                // largest lane offset: the block cannot touch the triangle if even that is negative
+                maxoff[i] = (e.A[i] > 0 ? (int64_t)e.A[i] * 1792 : 0) + (e.B[i] > 0 ? (int64_t)e.B[i] * 1792 : 0) + e.tlb[i];
+                // (products come out of the vector multiplier: back to scalar registers)
+                Er[i] = uniform_i64(Er[i]); stepx[i] = uniform_i64(stepx[i]);
+                stepy[i] = uniform_i64(stepy[i]); maxoff[i] = uniform_i64(maxoff[i]);
+            }
+            for (int qy = qy0; qy <= qy1; ++qy) {
+                int64_t E0 = Er[0], E1 = Er[1], E2 = Er[2];
+                for (int qx = qx0; qx <= qx1; ++qx) {
+                    // (keeps the stepped values in scalar registers: without this the compiler
+                    // steps per-lane copies of E + L for every block, rejected or not)
+                    asm volatile("" : "+s"(E0), "+s"(E1), "+s"(E2));
+                    const int64_t m0 = E0 + maxoff[0], m1 = E1 + maxoff[1], m2 = E2 + maxoff[2];
+                    bool skip = (m0 | m1 | m2) < 0;
+                    if (MODE == kRasterLayers) skip = skip || !((s_fmask >> (8 * (qy - (oy >> 3)) + (qx - (ox >> 3)))) & 1ull);
+                    if (!skip) {
+                        const int64_t T0 = E0 + L[0], T1 = E1 + L[1], T2 = E2 + L[2];
+                        if ((T0 | T1 | T2) >= 0) {
+                            float f1, f2;
+                            if ((m1 | m2) < (1ll << 30)) {
+                                // covered lanes have 0 <= T < 2^30: the low words are the values
+                                f1 = (float)((int32_t)T1 - e.tlb[1]);
+                                f2 = (float)((int32_t)T2 - e.tlb[2]);
+                            } else {
+                                f1 = (float)(T1 - e.tlb[1]);
+                                f2 = (float)(T2 - e.tlb[2]);
+                            }
+                            const float l1 = f1 * r.inv2A, l2 = f2 * r.inv2A;
+                            float z = (r.z0 + l1 * r.dz1) + l2 * r.dz2;
+                            z = fminf(fmaxf(z, 0.0f), 1.0f);
+                            raster_emit<MODE>(r, z, tile_index(qx * 8 - ox + lx, qy * 8 - oy + ly), tile, tile32, ls);
+                        }
+                    }
+                    E0 += stepx[0]; E1 += stepx[1]; E2 += stepx[2];
                 }
+                Er[0] += stepy[0]; Er[1] += stepy[1]; Er[2] += stepy[2];
+            }
         }
         __syncthreads();
     }
@@ -579,13 +629,14 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
         int px = ox + (i & (kBin - 1)), py = oy + (i / kBin);
         if (px >= W || py >= H) continue;
         size_t o = (size_t)layer * (size_t)W * (size_t)H + (size_t)py * W + px;
+        const int ti = tile_index(i & (kBin - 1), i / kBin);
         if (MODE == kRasterShadow) {
-            depth[o] = u2f(tile32[i]);
+            depth[o] = u2f(tile32[ti]);
         } else if (MODE == kRasterLayers) {
-            unsigned long long k = tile[i];
+            unsigned long long k = tile[ti];
             if ((uint32_t)k != 0u) ls.list_count[(uint32_t)k - 1u] = (uint32_t)(k >> 32);
         } else {
-            unsigned long long k = tile[i];
+            unsigned long long k = tile[ti];
             vis[o] = (uint32_t)k;
             depth[o] = u2f((uint32_t)(k >> 32));
         }
