@@ -578,33 +578,34 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
             const int x0 = imax((int)(r.bbmin & 0xffffu), ox), x1 = imin((int)(r.bbmax & 0xffffu), ox + kBin - 1);
             const int y0 = imax((int)(r.bbmin >> 16), oy), y1 = imin((int)(r.bbmax >> 16), oy + kBin - 1);
             const int qx0 = x0 >> 3, qx1 = x1 >> 3, qy0 = y0 >> 3, qy1 = y1 >> 3;
-            int64_t L[3], Er[3], stepx[3], stepy[3], maxoff[3];
-            edge_eval(e, qx0 * 8, qy0 * 8, Er);
+            // M[i]: the largest value edge function i (plus its fill-rule offset) takes on the
+            // 64 pixel centres of the current block, uniform and stepped from block to block;
+            // L[i]: what a lane adds to M[i] to get the value at its own pixel (<= 0).
+            int64_t L[3], Mr[3], stepx[3], stepy[3];
+            edge_eval(e, qx0 * 8, qy0 * 8, Mr);
             for (int i = 0; i < 3; ++i) {
-                L[i] = (int64_t)e.A[i] * (256 * lx) + (int64_t)e.B[i] * (256 * ly) + e.tlb[i];
-                stepx[i] = (int64_t)e.A[i] * 2048;
-                stepy[i] = (int64_t)e.B[i] * 2048;
-                // largest lane offset: the block cannot touch the triangle if even that is negative
-                maxoff[i] = (e.A[i] > 0 ? (int64_t)e.A[i] * 1792 : 0) + (e.B[i] > 0 ? (int64_t)e.B[i] * 1792 : 0) + e.tlb[i];
+                const int64_t maxoff = (e.A[i] > 0 ? (int64_t)e.A[i] * 1792 : 0) + (e.B[i] > 0 ? (int64_t)e.B[i] * 1792 : 0);
+                L[i] = ((int64_t)e.A[i] * (256 * lx) + (int64_t)e.B[i] * (256 * ly)) - maxoff;
                 // (products come out of the vector multiplier: back to scalar registers)
-                Er[i] = uniform_i64(Er[i]); stepx[i] = uniform_i64(stepx[i]);
-                stepy[i] = uniform_i64(stepy[i]); maxoff[i] = uniform_i64(maxoff[i]);
+                Mr[i] = uniform_i64(Mr[i] + maxoff + e.tlb[i]);
+                stepx[i] = uniform_i64((int64_t)e.A[i] * 2048);
+                stepy[i] = uniform_i64((int64_t)e.B[i] * 2048);
             }
             for (int qy = qy0; qy <= qy1; ++qy) {
-                int64_t E0 = Er[0], E1 = Er[1], E2 = Er[2];
+                int64_t M0 = Mr[0], M1 = Mr[1], M2 = Mr[2];
                 for (int qx = qx0; qx <= qx1; ++qx) {
                     // (keeps the stepped values in scalar registers: without this the compiler
-                    // steps per-lane copies of E + L for every block, rejected or not)
-                    asm volatile("" : "+s"(E0), "+s"(E1), "+s"(E2));
-                    const int64_t m0 = E0 + maxoff[0], m1 = E1 + maxoff[1], m2 = E2 + maxoff[2];
-                    bool skip = (m0 | m1 | m2) < 0;
+                    // steps per-lane copies of M + L for every block, rejected or not)
+                    asm volatile("" : "+s"(M0), "+s"(M1), "+s"(M2));
+                    // the block cannot touch the triangle if an edge is negative even at its best pixel
+                    bool skip = (M0 | M1 | M2) < 0;
                     if (MODE == kRasterLayers) skip = skip || !((s_fmask >> (8 * (qy - (oy >> 3)) + (qx - (ox >> 3)))) & 1ull);
                     if (!skip) {
-                        const int64_t T0 = E0 + L[0], T1 = E1 + L[1], T2 = E2 + L[2];
+                        const int64_t T0 = M0 + L[0], T1 = M1 + L[1], T2 = M2 + L[2];
                         if ((T0 | T1 | T2) >= 0) {
                             float f1, f2;
-                            if ((m1 | m2) < (1ll << 30)) {
-                                // covered lanes have 0 <= T < 2^30: the low words are the values
+                            if ((M1 | M2) < (1ll << 30)) {
+                                // covered lanes have 0 <= T <= M < 2^30: the low words are the values
                                 f1 = (float)((int32_t)T1 - e.tlb[1]);
                                 f2 = (float)((int32_t)T2 - e.tlb[2]);
                             } else {
@@ -617,9 +618,9 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
                             raster_emit<MODE>(r, z, tile_index(qx * 8 - ox + lx, qy * 8 - oy + ly), tile, tile32, ls);
                         }
                     }
-                    E0 += stepx[0]; E1 += stepx[1]; E2 += stepx[2];
+                    M0 += stepx[0]; M1 += stepx[1]; M2 += stepx[2];
                 }
-                Er[0] += stepy[0]; Er[1] += stepy[1]; Er[2] += stepy[2];
+                Mr[0] += stepy[0]; Mr[1] += stepy[1]; Mr[2] += stepy[2];
             }
         }
         __syncthreads();
