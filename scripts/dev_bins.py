@@ -43,3 +43,16 @@ for name, g, T, layers in (("shadow", 0, S, 6), ("geometry", 1, (W, H), 1)):
     print("  top bins by area (area, n, big):", [(int(area[i]), int(cnt[i]), int(big[i])) for i in order[:12]])
     o2 = np.argsort(-cnt.astype(np.int64))
     print("  top bins by count (area, n, big):", [(int(area[i]), int(cnt[i]), int(big[i])) for i in o2[:12]])
+# per-bin raster durations (wall clock ticks, 100 MHz)
+dbg = read(8).view(np.uint64).reshape(3, 40000)
+nbg = ((W + 63) // 64) * ((H + 63) // 64)
+cntg = read(1)
+for mode, name, nb_ in ((0, "colour", nbg), (2, "layers", nbg), (1, "shadow", 6144 * 6)):
+    t = dbg[mode, :nb_].astype(np.float64) / 100.0  # microseconds
+    o = np.argsort(-t)
+    print(f"== raster {name}: sum {t.sum():.0f} us, max {t.max():.1f}, p99 {np.percentile(t,99):.1f}, p90 {np.percentile(t,90):.1f}, median {np.median(t):.1f}")
+    if mode != 1:
+        print("   top (us, n items):", [(round(float(t[i]), 1), int(cntg[i])) for i in o[:16]])
+    else:
+        c = read(0)
+        print("   top (us, n items):", [(round(float(t[i]), 1), int(c[i])) for i in o[:16]])

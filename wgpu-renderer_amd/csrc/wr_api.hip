@@ -447,7 +447,7 @@ int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do
     // ordered blending of the pixels k_shade flagged: collect, order, shade, blend
     {
         const RasterWS& ws = ctx->geom.ws;
-        LayerSink ls{ctx->blend.rp_slot, ctx->blend.bin_flag, ctx->blend.lists, ctx->blend.list_count};
+        LayerSink ls{ctx->blend.rp_slot, ctx->d_vis, ctx->blend.bin_flag, ctx->blend.lists, ctx->blend.list_count, ctx->blend.cap};
         hipLaunchKernelGGL((k_raster<kRasterLayers, 1024>), dim3((uint32_t)(ws.bins_x * ws.bins_y), 1, 1), dim3(1024), 0,
                            ctx->stream, ws, ctx->W, ctx->H, (uint32_t*)nullptr, (float*)nullptr, fc.tile_rank, fc.tile_world, ls);
         const size_t npx = (size_t)ctx->W * ctx->H;
@@ -917,6 +917,12 @@ extern "C" int wr_dev_read(WrContext* ctx, int which, void* dst, size_t bytes) {
         case 3: src = ws.bin_items; have = (size_t)ws.items_cap * 4; break;
     }
     (void)hipStreamSynchronize(ctx->stream);
+    if ((which >> 1) == 4) {
+        have = sizeof(unsigned long long) * 3 * 40000;
+        if (bytes > have) bytes = have;
+        if (bytes && hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dbg_cycles), bytes) != hipSuccess) return -1;
+        return (int)(have / 4);
+    }
     if (bytes > have) bytes = have;
     if (hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return (int)(have / 4 > 0x7fffffff ? 0x7fffffff : have / 4);

@@ -353,15 +353,27 @@ struct ColorTables {
     WR_HD float unorm(uint32_t c) const { return t[256 + c]; }
     WR_HD float thresh(uint32_t c) const { return t[512 + c]; }
 };
+// Largest code c with thresh(c) <= x.  On the device the search starts from an estimate
+// (hardware log2/exp2 of the sRGB curve, a code or so off at worst) and walks to the code
+// the thresholds define; the host build bisects.  Both return the same code.
 WR_HD uint32_t srgb_encode(const ColorTables& ct, float x) {
     if (!(x > 0.0f)) return 0;
     if (x >= 1.0f) return 255;
+#if defined(__HIP_DEVICE_COMPILE__)
+    float est = x <= 0.0031308f ? x * 3294.6f : 269.025f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * 0.41666666f) - 14.025f;
+    int g = (int)(est + 0.5f);
+    g = g < 0 ? 0 : (g > 255 ? 255 : g);
+    while (g < 255 && x >= ct.thresh((uint32_t)(g + 1))) ++g;
+    while (g > 0 && x < ct.thresh((uint32_t)g)) --g;
+    return (uint32_t)g;
+#else
     int lo = 0, hi = 255;
     for (int it = 0; it < 8; ++it) {
         int mid = (lo + hi + 1) >> 1;
         if (x >= ct.thresh((uint32_t)mid)) lo = mid; else hi = mid - 1;
     }
     return (uint32_t)lo;
+#endif
 }
 WR_HD uint32_t unorm_encode(float a) {
     if (!(a > 0.0f)) return 0;

@@ -422,9 +422,11 @@ constexpr int kReplayK = 16;  // covering fragments kept per flagged pixel befor
 // Where k_raster<kRasterLayers> puts the fragments of pixels flagged for ordered blending.
 struct LayerSink {
     const uint32_t* rp_slot;   // [H][W] list slot + 1 of a flagged pixel, else 0
+    const uint32_t* vis;       // [H][W] id of the front-most fragment
     const uint32_t* bin_flag;  // [bins] non-zero: the bin holds a flagged pixel
-    uint2* lists;              // [slots][kReplayK] (id, depth bits)
-    uint32_t* list_count;      // [slots] fragments seen (may exceed kReplayK)
+    uint2* lists;              // [kReplayK][cap] (id, depth bits): entry c of slot s at c * cap + s
+    uint32_t* list_count;      // [cap] fragments seen (may exceed kReplayK)
+    uint32_t cap;
 };
 
 // A record every lane of the wavefront holds a copy of, moved to scalar registers: what is
@@ -463,9 +465,18 @@ __device__ inline void raster_emit(const Rec& r, float z, int li, unsigned long 
         if (z < 1.0f) atomicMin(&tile[li], ((unsigned long long)f2u(z) << 32) | (unsigned long long)r.id);
     } else {
         if (reinterpret_cast<const uint32_t*>(tile)[2 * li] == 0u) return;
+        // a fragment drawn after the front-most one failed the depth test against it
+        if (r.id > tile32[li]) return;
+#if defined(WR_ABLATE) && (WR_ABLATE & 8)
+        unsigned long long old = tile[li];
+#else
         unsigned long long old = atomicAdd(&tile[li], 1ull << 32);
+#endif
         uint32_t c = (uint32_t)(old >> 32);
-        if (c < (uint32_t)kReplayK) ls.lists[(size_t)((uint32_t)old - 1u) * kReplayK + c] = make_uint2(r.id, f2u(z));
+#if defined(WR_ABLATE) && (WR_ABLATE & 4)
+        if (c == 77u)
+#endif
+        if (c < (uint32_t)kReplayK) ls.lists[(size_t)c * ls.cap + ((uint32_t)old - 1u)] = make_uint2(r.id, f2u(z));
     }
 }
 
@@ -475,16 +486,22 @@ __device__ inline void raster_emit(const Rec& r, float z, int li, unsigned long 
 // THREADS: 256 for the shadow faces (6144 mostly short lists: more bins in flight per CU),
 // 1024 for the colour target (few bins, some with thousands of triangles: 16 wavefronts
 // sharing the tile shorten the longest lists).
+#ifdef WR_DEV
+__device__ unsigned long long g_dbg_cycles[3 * 40000];
+#endif
 template <int MODE, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, uint32_t* vis, float* depth,
                                                     int tile_rank, int tile_world, LayerSink ls) {
     constexpr int kRasterThreads = THREADS;
     __shared__ unsigned long long tile[MODE == kRasterShadow ? 1 : kBin * kBin];
-    __shared__ uint32_t tile32[MODE == kRasterShadow ? kBin * kBin : 1];
+    __shared__ uint32_t tile32[MODE == kRasterColor ? 1 : kBin * kBin];  // layers: id of the front-most fragment
     __shared__ uint32_t bigq[kRasterThreads];  // record indices of the chunk's large triangles
     __shared__ uint32_t s_nbig;
     __shared__ unsigned long long s_fmask;  // layers: bit (8*by + bx) set = 8x8 block holds a flagged pixel
     const int b = blockIdx.x, layer = blockIdx.y;
+#ifdef WR_DEV
+    const unsigned long long dbg_t0 = wall_clock64();
+#endif
     if (!bin_owned(b, tile_rank, tile_world)) return;
     if (MODE == kRasterLayers && ls.bin_flag[b] == 0u) return;
     const int bx = b % ws.bins_x, by = b / ws.bins_x;
@@ -501,6 +518,7 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
             int px = ox + (i & (kBin - 1)), py = oy + (i / kBin);
             uint32_t slot = (px < W && py < H) ? ls.rp_slot[(size_t)py * W + px] : 0u;
             tile[tile_index(i & (kBin - 1), i / kBin)] = (unsigned long long)slot;
+            tile32[tile_index(i & (kBin - 1), i / kBin)] = slot ? ls.vis[(size_t)py * W + px] : 0u;
             unsigned long long m = __ballot(slot != 0u);
             m |= m >> 4; m |= m >> 2; m |= m >> 1;
             m &= 0x0101010101010101ull;
@@ -535,6 +553,12 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
                     wanted = ((cols * 0x0101010101010101ull) & rows & s_fmask) != 0ull;
                 }
             }
+#if defined(WR_ABLATE) && (WR_ABLATE & 16)
+            if (MODE == kRasterLayers && fw <= 64 * 256 && fh <= 64 * 256 && (x1 - x0 + 1) * (y1 - y0 + 1) <= WR_RASTER_LANE_AREA) wanted = false;
+#endif
+#if defined(WR_ABLATE) && (WR_ABLATE & 32)
+            if (MODE == kRasterLayers && !(fw <= 64 * 256 && fh <= 64 * 256 && (x1 - x0 + 1) * (y1 - y0 + 1) <= WR_RASTER_LANE_AREA)) wanted = false;
+#endif
             if (!wanted) {
             } else if (fw <= 64 * 256 && fh <= 64 * 256 && (x1 - x0 + 1) * (y1 - y0 + 1) <= WR_RASTER_LANE_AREA) {
                 // The triangle's vertices span at most 64x64 pixels, so every edge function
@@ -567,60 +591,54 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
         __syncthreads();
         const uint32_t nbig = s_nbig;
         for (uint32_t q = wave; q < nbig; q += kRasterThreads / 64) {
-            // Wave-uniform record: scalar loads, edge set-up on the scalar unit.  An edge
-            // function at pixel (8 qx + lx, 8 qy + ly) is a uniform 64-bit value stepped from
-            // block to block plus a per-lane offset fixed per triangle (fill-rule offset
-            // included), so a block costs three 64-bit adds and a sign test per lane.
+            // Wave-uniform record.  Step 1: lane (bx, by) classifies 8x8 pixel block (bx, by)
+            // of the bin: M[i] is the largest value edge function i (plus its fill-rule
+            // offset) takes on the block's 64 pixel centres; the block cannot touch the
+            // triangle if any M[i] is negative.  Step 2: the blocks that can are visited one
+            // by one, lane (lx, ly) testing pixel (lx, ly) of the block: its edge values are
+            // the block's M[i] (fetched from the classifying lane) plus a per-lane offset
+            // L[i] <= 0 fixed per triangle.  Rejected blocks cost nothing in step 2.
             const uint32_t ri = __builtin_amdgcn_readfirstlane(bigq[q]);
             const Rec r = uniform_rec(load_rec(&recs[ri]));
             Edges e;
             make_edges(r, e);
             const int x0 = imax((int)(r.bbmin & 0xffffu), ox), x1 = imin((int)(r.bbmax & 0xffffu), ox + kBin - 1);
             const int y0 = imax((int)(r.bbmin >> 16), oy), y1 = imin((int)(r.bbmax >> 16), oy + kBin - 1);
-            const int qx0 = x0 >> 3, qx1 = x1 >> 3, qy0 = y0 >> 3, qy1 = y1 >> 3;
-            // M[i]: the largest value edge function i (plus its fill-rule offset) takes on the
-            // 64 pixel centres of the current block, uniform and stepped from block to block;
-            // L[i]: what a lane adds to M[i] to get the value at its own pixel (<= 0).
-            int64_t L[3], Mr[3], stepx[3], stepy[3];
-            edge_eval(e, qx0 * 8, qy0 * 8, Mr);
+            int64_t L[3], Mv[3], Mo[3];
+            edge_eval(e, ox, oy, Mo);
             for (int i = 0; i < 3; ++i) {
                 const int64_t maxoff = (e.A[i] > 0 ? (int64_t)e.A[i] * 1792 : 0) + (e.B[i] > 0 ? (int64_t)e.B[i] * 1792 : 0);
                 L[i] = ((int64_t)e.A[i] * (256 * lx) + (int64_t)e.B[i] * (256 * ly)) - maxoff;
-                // (products come out of the vector multiplier: back to scalar registers)
-                Mr[i] = uniform_i64(Mr[i] + maxoff + e.tlb[i]);
-                stepx[i] = uniform_i64((int64_t)e.A[i] * 2048);
-                stepy[i] = uniform_i64((int64_t)e.B[i] * 2048);
+                Mv[i] = (Mo[i] + maxoff + e.tlb[i]) + ((int64_t)e.A[i] * (2048 * lx) + (int64_t)e.B[i] * (2048 * ly));
             }
-            for (int qy = qy0; qy <= qy1; ++qy) {
-                int64_t M0 = Mr[0], M1 = Mr[1], M2 = Mr[2];
-                for (int qx = qx0; qx <= qx1; ++qx) {
-                    // (keeps the stepped values in scalar registers: without this the compiler
-                    // steps per-lane copies of M + L for every block, rejected or not)
-                    asm volatile("" : "+s"(M0), "+s"(M1), "+s"(M2));
-                    // the block cannot touch the triangle if an edge is negative even at its best pixel
-                    bool skip = (M0 | M1 | M2) < 0;
-                    if (MODE == kRasterLayers) skip = skip || !((s_fmask >> (8 * (qy - (oy >> 3)) + (qx - (ox >> 3)))) & 1ull);
-                    if (!skip) {
-                        const int64_t T0 = M0 + L[0], T1 = M1 + L[1], T2 = M2 + L[2];
-                        if ((T0 | T1 | T2) >= 0) {
-                            float f1, f2;
-                            if ((M1 | M2) < (1ll << 30)) {
-                                // covered lanes have 0 <= T <= M < 2^30: the low words are the values
-                                f1 = (float)((int32_t)T1 - e.tlb[1]);
-                                f2 = (float)((int32_t)T2 - e.tlb[2]);
-                            } else {
-                                f1 = (float)(T1 - e.tlb[1]);
-                                f2 = (float)(T2 - e.tlb[2]);
-                            }
-                            const float l1 = f1 * r.inv2A, l2 = f2 * r.inv2A;
-                            float z = (r.z0 + l1 * r.dz1) + l2 * r.dz2;
-                            z = fminf(fmaxf(z, 0.0f), 1.0f);
-                            raster_emit<MODE>(r, z, tile_index(qx * 8 - ox + lx, qy * 8 - oy + ly), tile, tile32, ls);
-                        }
-                    }
-                    M0 += stepx[0]; M1 += stepx[1]; M2 += stepx[2];
+            const bool in_box = lx >= ((x0 - ox) >> 3) && lx <= ((x1 - ox) >> 3) && ly >= ((y0 - oy) >> 3) && ly <= ((y1 - oy) >> 3);
+            unsigned long long todo = __ballot(in_box && (Mv[0] | Mv[1] | Mv[2]) >= 0);
+            if (MODE == kRasterLayers) todo &= s_fmask;
+            // blocks whose covered pixels have edge values below 2^30 (0 <= value <= M)
+            const unsigned long long narrow = __ballot((Mv[1] | Mv[2]) < (1ll << 30));
+            while (todo) {
+                const int blk = (int)__builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                int64_t T[3];
+                for (int i = 0; i < 3; ++i) {
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)Mv[i], blk);
+                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)Mv[i] >> 32), blk);
+                    T[i] = (int64_t)(((uint64_t)hi << 32) | lo) + L[i];
                 }
-                Mr[0] += stepy[0]; Mr[1] += stepy[1]; Mr[2] += stepy[2];
+                if ((T[0] | T[1] | T[2]) >= 0) {
+                    float f1, f2;
+                    if ((narrow >> blk) & 1ull) {
+                        f1 = (float)((int32_t)T[1] - e.tlb[1]);
+                        f2 = (float)((int32_t)T[2] - e.tlb[2]);
+                    } else {
+                        f1 = (float)(T[1] - e.tlb[1]);
+                        f2 = (float)(T[2] - e.tlb[2]);
+                    }
+                    const float l1 = f1 * r.inv2A, l2 = f2 * r.inv2A;
+                    float z = (r.z0 + l1 * r.dz1) + l2 * r.dz2;
+                    z = fminf(fmaxf(z, 0.0f), 1.0f);
+                    raster_emit<MODE>(r, z, tile_index((blk & 7) * 8 + lx, (blk >> 3) * 8 + ly), tile, tile32, ls);
+                }
             }
         }
         __syncthreads();
@@ -642,6 +660,9 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
             depth[o] = u2f((uint32_t)(k >> 32));
         }
     }
+#ifdef WR_DEV
+    if (threadIdx.x == 0) g_dbg_cycles[MODE * 40000 + (int)gb] = wall_clock64() - dbg_t0;
+#endif
 }
 
 // ------------------------------------------------------------------ deferred shading
@@ -652,7 +673,7 @@ struct BlendWS {
     uint32_t* slot_pixel;  // [cap] pixel index of a slot
     uint32_t* counts;      // [0] flagged pixels, [1] fragments to shade, [2] slow pixels; cleared every frame
     uint32_t* bin_flag;    // [bins] bin holds a flagged pixel; cleared every frame
-    uint2* lists;          // [cap][kReplayK] (id, depth bits) of the fragments covering a flagged pixel
+    uint2* lists;          // [kReplayK][cap] (id, depth bits) of the fragments covering a flagged pixel
     uint32_t* list_count;  // [cap]
     uint32_t* slow_slots;  // [cap] slots left to k_replay_slow
     uint2* slot_frags;     // [cap] first fragment item, number of items (kSlotDone: colour already final)
@@ -681,11 +702,17 @@ struct ShadeArgs {
     BlendWS bw;
 };
 
+// Copies the colour tables (decode | unorm | thresh, 768 floats) to LDS; ends with a barrier.
+__device__ inline void stage_color_tables(float* s_tab, const float* tables) {
+    for (int i = (int)threadIdx.x; i < 768; i += (int)blockDim.x) s_tab[i] = tables[i];
+    __syncthreads();
+}
+
 // Interpolates the VertexOutput of one fragment and runs pbr.wgsl's fs_main on it.
 // Derivatives for the sampler's level of detail are taken per 2x2 quad on the fragment's
 // own triangle: ddx = uv(x0+1,y0) - uv(x0,y0), ddy = uv(x0,y0+1) - uv(x0,y0).
-__device__ inline V4 shade_fragment(const ShadeArgs& a, const Rec& r, const float* beta, const Edges& e,
-                                    uint32_t tri, int px, int py, const int64_t* E) {
+__device__ inline V4 shade_fragment(const ShadeArgs& a, const float* color_tables, const Rec& r, const float* beta,
+                                    const Edges& e, uint32_t tri, int px, int py, const int64_t* E) {
     uint32_t i0 = a.idx[3 * tri], i1 = a.idx[3 * tri + 1], i2 = a.idx[3 * tri + 2];
     float4 a0 = a.v0[i0], a1 = a.v0[i1], a2 = a.v0[i2];
     float B[3];
@@ -711,7 +738,7 @@ __device__ inline V4 shade_fragment(const ShadeArgs& a, const Rec& r, const floa
     in.tview = v3(ip(B, c0.x, c1.x, c2.x), ip(B, c0.y, c1.y, c2.y), ip(B, c0.z, c1.z, c2.z));
     in.wpos = V4{ip(B, c0.w, c1.w, c2.w), ip(B, d0.x, d1.x, d2.x), ip(B, d0.y, d1.y, d2.y), ip(B, d0.z, d1.z, d2.z)};
     ShadowMap sm{a.shadow, a.fc.S};
-    ColorTables ct{a.tables};
+    ColorTables ct{color_tables};
     return fs_pbr(a.fc, sm, a.texels, a.tex, a.mats[a.tri_mat[tri]], ct, in);
 }
 
@@ -770,7 +797,7 @@ __device__ __attribute__((noinline)) uint32_t replay_pixel(const ShadeArgs& a, i
             make_edges(r, e);
             int64_t E[3];
             edge_eval(e, px, py, E);
-            V4 src = shade_fragment(a, r, beta, e, tri, px, py, E);
+            V4 src = shade_fragment(a, a.tables, r, beta, e, tri, px, py, E);
             col = blend_pack(ct, col, src, true);
         }
         d = best_z;
@@ -782,6 +809,7 @@ __device__ __attribute__((noinline)) uint32_t replay_pixel(const ShadeArgs& a, i
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
     __shared__ uint32_t s_cnt, s_base;
+    __shared__ float s_tab[768];
     // 16x16 pixels per workgroup, each wavefront an 8x8 block
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
@@ -791,7 +819,8 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
     const bool live = px < a.fc.W && py < a.fc.H;
     const size_t pi = (size_t)py * a.fc.W + px;
     const uint32_t id = live ? a.vis[pi] : kVisNone;
-    ColorTables ct{a.tables};
+    stage_color_tables(s_tab, a.tables);
+    ColorTables ct{s_tab};
     bool flagged = false;
     if (id == kVisNone) {
         if (live) a.color[pi] = 0xFF000000u;  // clear colour (0,0,0,1), state.rs:696-701
@@ -805,7 +834,7 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
         make_edges(r, e);
         int64_t E[3];
         edge_eval(e, px, py, E);
-        V4 src = shade_fragment(a, r, beta, e, tri, px, py, E);
+        V4 src = shade_fragment(a, s_tab, r, beta, e, tri, px, py, E);
         if (COUNT) atomicAdd(&a.counters[2], 1ull);
         if (src.w == 1.0f) {
             a.color[pi] = blend_pack(ct, 0u, src, false);  // alpha 1 replaces whatever was blended before
@@ -851,15 +880,14 @@ __global__ __launch_bounds__(256) void k_resolve(ShadeArgs a) {
         int np = 0, start = 0;
         if (live && !slow) {
             // the whole list in flight at once, then insertion by ascending id = draw order
-            const uint4* row = reinterpret_cast<const uint4*>(bw.lists + (size_t)s * kReplayK);
-            uint4 q[kReplayK / 2];
+            uint2 q[kReplayK];
 #pragma unroll
-            for (int i = 0; i < kReplayK / 2; ++i) q[i] = (uint32_t)(2 * i) < cnt ? row[i] : make_uint4(0u, 0u, 0u, 0u);
+            for (int i = 0; i < kReplayK; ++i) q[i] = (uint32_t)i < cnt ? bw.lists[(size_t)i * bw.cap + s] : make_uint2(0u, 0u);
 #pragma unroll
             for (int i = 0; i < kReplayK; ++i) {
                 if ((uint32_t)i < cnt) {
-                    const uint32_t id = (i & 1) ? q[i >> 1].z : q[i >> 1].x;
-                    const float z = u2f((i & 1) ? q[i >> 1].w : q[i >> 1].y);
+                    const uint32_t id = q[i].x;
+                    const float z = u2f(q[i].y);
                     int j = i - 1;
                     while (j >= 0 && cid[j][tid] > id) { cid[j + 1][tid] = cid[j][tid]; cz[j + 1][tid] = cz[j][tid]; --j; }
                     cid[j + 1][tid] = id; cz[j + 1][tid] = z;
@@ -912,7 +940,10 @@ __global__ __launch_bounds__(64) void k_replay_slow(ShadeArgs a) {
 // Ordered blending, step 3: one thread per fragment item runs pbr.wgsl's fs_main (the light
 // marker, drawn with REPLACE, has a constant colour: light_debug.wgsl:23-26).
 __global__ __launch_bounds__(64) void k_shade_frags(ShadeArgs a) {
+    __shared__ float s_tab[768];
     const BlendWS& bw = a.bw;
+    if (blockIdx.x * 64u >= min(bw.counts[1], bw.frag_cap)) return;
+    stage_color_tables(s_tab, a.tables);
     const uint32_t n = min(bw.counts[1], bw.frag_cap);
     for (uint32_t f = blockIdx.x * 64u + threadIdx.x; f < n; f += gridDim.x * 64u) {
         const uint2 it = bw.frag_item[f];
@@ -928,7 +959,7 @@ __global__ __launch_bounds__(64) void k_shade_frags(ShadeArgs a) {
             make_edges(r, e);
             int64_t E[3];
             edge_eval(e, px, py, E);
-            src = shade_fragment(a, r, beta, e, tri, px, py, E);
+            src = shade_fragment(a, s_tab, r, beta, e, tri, px, py, E);
         }
         bw.frag_src[f] = make_float4(src.x, src.y, src.z, src.w);
     }
@@ -938,9 +969,12 @@ __global__ __launch_bounds__(64) void k_shade_frags(ShadeArgs a) {
 // order (geometry: SrcAlpha/OneMinusSrcAlpha, state.rs:465-467; light marker: REPLACE,
 // state.rs:480-482).
 __global__ __launch_bounds__(256) void k_blend(ShadeArgs a) {
+    __shared__ float s_tab[768];
     const BlendWS& bw = a.bw;
-    ColorTables ct{a.tables};
     const uint32_t nslots = min(bw.counts[0], bw.cap);
+    if (blockIdx.x * 256u >= nslots) return;
+    stage_color_tables(s_tab, a.tables);
+    ColorTables ct{s_tab};
     for (uint32_t s = blockIdx.x * 256u + threadIdx.x; s < nslots; s += gridDim.x * 256u) {
         const uint2 fr = bw.slot_frags[s];
         if (fr.y == kSlotDone) continue;
