@@ -68,6 +68,10 @@ struct WrContext {
     int W = 0, H = 0, S = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // The shadow pass and the fog pass's preparation depend only on the frame's uniforms, so
+    // they run on a side stream next to the geometry pass; the shading kernels wait for them.
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
 
     ModelHost host[3];
@@ -100,7 +104,8 @@ struct WrContext {
     // Profiling keeps one set of five stage-boundary events per frame in a ring; wr_get_stats
     // averages the stage times over the frames recorded since profiling was switched on.
     static constexpr int kEvFrames = 128;
-    hipEvent_t ev[kEvFrames][5] = {};
+    static constexpr int kEvPerFrame = 6;  // frame start | shadow start, end (side stream) | geometry, shade, fog end
+    hipEvent_t ev[kEvFrames][kEvPerFrame] = {};
     int ev_count = 0;  // frames recorded since wr_set_profiling(1), saturates at kEvFrames
     int ev_next = 0;
     WrFrameStats stats{};
@@ -344,28 +349,28 @@ FrameConsts make_consts(const WrContext* ctx, const WrCameraUniform* cam, const 
 
 dim3 grid1(uint32_t n, uint32_t layers = 1) { return dim3((n + 255u) / 256u, layers, 1); }
 
-int bin_and_raster(WrContext* ctx, WsAlloc& w, bool shadow, int tr, int tw) {
+int bin_and_raster(WrContext* ctx, hipStream_t st, WsAlloc& w, bool shadow, int tr, int tw) {
     RasterWS& ws = w.ws;
     uint32_t nrec = ws.slots + ws.ovf_cap;
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, ctx->stream, ws);
-    hipLaunchKernelGGL(k_bin_fill, grid1(nrec, ws.layers), dim3(256), 0, ctx->stream, ws, tr, tw);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, ws);
+    hipLaunchKernelGGL(k_bin_fill, grid1(nrec, ws.layers), dim3(256), 0, st, ws, tr, tw);
     dim3 g((uint32_t)(ws.bins_x * ws.bins_y), (uint32_t)ws.layers, 1);
     if (shadow)
-        hipLaunchKernelGGL((k_raster<kRasterShadow, 256>), g, dim3(256), 0, ctx->stream, ws, ctx->S, ctx->S, (uint32_t*)nullptr,
+        hipLaunchKernelGGL((k_raster<kRasterShadow, 256>), g, dim3(256), 0, st, ws, ctx->S, ctx->S, (uint32_t*)nullptr,
                            ctx->d_shadow, 0, 1, LayerSink{});
     else
-        hipLaunchKernelGGL((k_raster<kRasterColor, 1024>), g, dim3(1024), 0, ctx->stream, ws, ctx->W, ctx->H, ctx->d_vis,
+        hipLaunchKernelGGL((k_raster<kRasterColor, 1024>), g, dim3(1024), 0, st, ws, ctx->W, ctx->H, ctx->d_vis,
                            ctx->d_depth, tr, tw, LayerSink{});
     return WR_OK;
 }
 
-int shadow_stage(WrContext* ctx, const FrameConsts& fc) {
+int shadow_stage(WrContext* ctx, hipStream_t st, const FrameConsts& fc) {
     const ModelDev& g = ctx->dev[WR_MODEL_GEOMETRY];
-    WR_HIP(hipMemsetAsync(ctx->shadow.counters, 0, ctx->shadow.counters_bytes, ctx->stream));
-    hipLaunchKernelGGL(k_vs_shadow, grid1(g.nv, 6), dim3(256), 0, ctx->stream, g.pos, g.nv, ctx->d_shadow_clip, fc);
-    hipLaunchKernelGGL(k_setup<true>, grid1(g.ntris, 6), dim3(256), 0, ctx->stream, ctx->d_shadow_clip, g.nv, g.idx, g.ntris,
+    WR_HIP(hipMemsetAsync(ctx->shadow.counters, 0, ctx->shadow.counters_bytes, st));
+    hipLaunchKernelGGL(k_vs_shadow, grid1(g.nv, 6), dim3(256), 0, st, g.pos, g.nv, ctx->d_shadow_clip, fc);
+    hipLaunchKernelGGL(k_setup<true>, grid1(g.ntris, 6), dim3(256), 0, st, ctx->d_shadow_clip, g.nv, g.idx, g.ntris,
                        ctx->shadow.ws, ctx->S, ctx->S, 0, 1);
-    return bin_and_raster(ctx, ctx->shadow, true, 0, 1);
+    return bin_and_raster(ctx, st, ctx->shadow, true, 0, 1);
 }
 
 // Chooses which noise levels get a hash table this frame.  Every march sample lies within
@@ -417,9 +422,26 @@ int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do
     hipEvent_t* ev = ctx->ev[ctx->ev_next];
     int rc;
     if (prof) WR_HIP(hipEventRecord(ev[0], ctx->stream));
+    const bool fog_pass = (passes & WR_PASS_FOG) && fm.ntris;
+    FogArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    // side stream: shadow maps, fog volume set-up, noise tables
+    WR_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+    WR_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+    if (prof) WR_HIP(hipEventRecord(ev[1], ctx->side));
     if (do_shadow && (passes & WR_PASS_SHADOWS))
-        if ((rc = shadow_stage(ctx, fc)) != WR_OK) return rc;
-    if (prof) WR_HIP(hipEventRecord(ev[1], ctx->stream));
+        if ((rc = shadow_stage(ctx, ctx->side, fc)) != WR_OK) return rc;
+    if (prof) WR_HIP(hipEventRecord(ev[2], ctx->side));
+    if (fog_pass) {
+        WR_HIP(hipMemsetAsync(ctx->fog.counters, 0, ctx->fog.counters_bytes, ctx->side));
+        hipLaunchKernelGGL(k_setup_small, grid1(fm.ntris), dim3(256), 0, ctx->side, fm.pos, fm.idx, fm.ntris, 1, 1, 0u,
+                           ctx->fog.ws, fc);
+        uint32_t max_entries = 0;
+        fa.tables_noise = plan_noise_tables(ctx, fc, &max_entries);
+        if (max_entries)
+            hipLaunchKernelGGL(k_fog_tables, dim3((max_entries + 255u) / 256u, 16, 1), dim3(256), 0, ctx->side, fa.tables_noise);
+    }
+    WR_HIP(hipEventRecord(ctx->ev_join, ctx->side));
 
     // geometry + light marker -> visibility / depth
     WR_HIP(hipMemsetAsync(ctx->geom.counters, 0, ctx->geom.counters_bytes, ctx->stream));
@@ -430,8 +452,9 @@ int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do
     if (lm.ntris)
         hipLaunchKernelGGL(k_setup_small, grid1(lm.ntris), dim3(256), 0, ctx->stream, lm.pos, lm.idx, lm.ntris, 0,
                            (passes & WR_PASS_LIGHT_DEBUG) ? 1 : 0, g.ntris, ctx->geom.ws, fc);
-    if ((rc = bin_and_raster(ctx, ctx->geom, false, fc.tile_rank, fc.tile_world)) != WR_OK) return rc;
-    if (prof) WR_HIP(hipEventRecord(ev[2], ctx->stream));
+    if ((rc = bin_and_raster(ctx, ctx->stream, ctx->geom, false, fc.tile_rank, fc.tile_world)) != WR_OK) return rc;
+    if (prof) WR_HIP(hipEventRecord(ev[3], ctx->stream));
+    WR_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));  // shading reads the shadow maps
 
     ShadeArgs sa;
     sa.fc = fc; sa.ws = ctx->geom.ws; sa.vis = ctx->d_vis; sa.depth = ctx->d_depth; sa.color = ctx->d_color;
@@ -458,22 +481,14 @@ int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do
         hipLaunchKernelGGL(k_shade_frags, dim3((uint32_t)std::min<size_t>((npx + 63) / 64, 16384)), dim3(64), 0, ctx->stream, sa);
         hipLaunchKernelGGL(k_blend, dim3(slot_groups), dim3(256), 0, ctx->stream, sa);
     }
-    if (prof) WR_HIP(hipEventRecord(ev[3], ctx->stream));
+    if (prof) WR_HIP(hipEventRecord(ev[4], ctx->stream));
 
-    if ((passes & WR_PASS_FOG) && fm.ntris) {
-        WR_HIP(hipMemsetAsync(ctx->fog.counters, 0, ctx->fog.counters_bytes, ctx->stream));
-        hipLaunchKernelGGL(k_setup_small, grid1(fm.ntris), dim3(256), 0, ctx->stream, fm.pos, fm.idx, fm.ntris, 1, 1, 0u,
-                           ctx->fog.ws, fc);
-        FogArgs fa;
+    if (fog_pass) {
         fa.fc = fc; fa.ws = ctx->fog.ws; fa.pos = fm.pos; fa.idx = fm.idx; fa.ntris = fm.ntris;
         fa.depth = ctx->d_depth; fa.color = ctx->d_color; fa.shadow = ctx->d_shadow; fa.tables = ctx->d_tables;
         fa.counters = ctx->d_counters;
         // the fog workspace has one bin, so its bin_count word is free: it counts march items
         fa.item_count = ctx->fog.ws.bin_count; fa.item_pixel = ctx->d_fog_pixel; fa.item_ray = ctx->d_fog_ray;
-        uint32_t max_entries = 0;
-        fa.tables_noise = plan_noise_tables(ctx, fc, &max_entries);
-        if (max_entries)
-            hipLaunchKernelGGL(k_fog_tables, dim3((max_entries + 255u) / 256u, 16, 1), dim3(256), 0, ctx->stream, fa.tables_noise);
         dim3 mg((uint32_t)(((size_t)ctx->W * ctx->H + 63) / 64), 1, 1);
         dim3 fg((uint32_t)(ctx->W + kFogBlock - 1) / kFogBlock, (uint32_t)(ctx->H + kFogBlock - 1) / kFogBlock, 1);
         if (ctx->counting) {
@@ -485,7 +500,7 @@ int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do
         }
     }
     if (prof) {
-        WR_HIP(hipEventRecord(ev[4], ctx->stream));
+        WR_HIP(hipEventRecord(ev[5], ctx->stream));
         ctx->ev_next = (ctx->ev_next + 1) % WrContext::kEvFrames;
         if (ctx->ev_count < WrContext::kEvFrames) ++ctx->ev_count;
     }
@@ -532,7 +547,10 @@ int wr_create(const WrConfig* config, WrContext** out_ctx) {
         if (config->stream) ctx->stream = (hipStream_t)config->stream;
         else { WR_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
         for (int f = 0; f < WrContext::kEvFrames; ++f)
-            for (int i = 0; i < 5; ++i) WR_HIP(hipEventCreate(&ctx->ev[f][i]));
+            for (int i = 0; i < WrContext::kEvPerFrame; ++i) WR_HIP(hipEventCreate(&ctx->ev[f][i]));
+        WR_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        WR_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        WR_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
         float tables[768];
         build_tables(tables);
         WR_HIP(hipMalloc(&ctx->d_tables, sizeof(tables)));
@@ -562,7 +580,10 @@ void wr_destroy(WrContext* ctx) {
     free_targets(ctx);
     dfree(ctx->d_tables); dfree(ctx->d_counters); dfree(ctx->d_err); dfree(ctx->d_shadow); dfree(ctx->d_noise_pool);
     for (int f = 0; f < WrContext::kEvFrames; ++f)
-        for (int i = 0; i < 5; ++i) if (ctx->ev[f][i]) (void)hipEventDestroy(ctx->ev[f][i]);
+        for (int i = 0; i < WrContext::kEvPerFrame; ++i) if (ctx->ev[f][i]) (void)hipEventDestroy(ctx->ev[f][i]);
+    if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -750,17 +771,19 @@ int wr_get_stats(WrContext* ctx, WrFrameStats* out) {
     int rc = wr_sync(ctx);
     if (rc != WR_OK) return rc;
     if (ctx->ev_count > 0) {
-        double ms[4] = {0, 0, 0, 0};
+        // shadow runs on the side stream next to geometry; shade includes any wait for it
+        const int a[5] = {1, 0, 3, 4, 0}, b[5] = {2, 3, 4, 5, 5};  // shadow, geometry, shade, fog, frame
+        double ms[5] = {0, 0, 0, 0, 0};
         for (int f = 0; f < ctx->ev_count; ++f)
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 5; ++i) {
                 float t = 0.0f;
-                WR_HIP(hipEventElapsedTime(&t, ctx->ev[f][i], ctx->ev[f][i + 1]));
+                WR_HIP(hipEventElapsedTime(&t, ctx->ev[f][a[i]], ctx->ev[f][b[i]]));
                 ms[i] += t;
             }
-        for (int i = 0; i < 4; ++i) ms[i] /= ctx->ev_count;
+        for (int i = 0; i < 5; ++i) ms[i] /= ctx->ev_count;
         ctx->stats.ms_shadow = (float)ms[0]; ctx->stats.ms_geometry = (float)ms[1];
         ctx->stats.ms_shade = (float)ms[2]; ctx->stats.ms_fog = (float)ms[3];
-        ctx->stats.ms_total = (float)(ms[0] + ms[1] + ms[2] + ms[3]);
+        ctx->stats.ms_total = (float)ms[4];
         ctx->stats.profiled_frames = (uint32_t)ctx->ev_count;
     }
     unsigned long long c[8];
