@@ -454,7 +454,8 @@ __device__ inline int tile_index(int x, int y) { return y * kBin + (x ^ ((y & 7)
 
 // One covered sample.  Colour: depth test Less with depth write, the smallest (depth, id)
 // key wins.  Shadow: min of the biased depth.  Layers: a flagged pixel's tile word holds
-// its list slot + 1 in the low half and the fragments seen so far in the high half.
+// its list slot + 1 (low half) and the id of its front-most fragment (high half), tile32
+// counts the fragments appended so far.
 template <int MODE>
 __device__ inline void raster_emit(const Rec& r, float z, int li, unsigned long long* tile, uint32_t* tile32,
                                    const LayerSink& ls) {
@@ -464,19 +465,12 @@ __device__ inline void raster_emit(const Rec& r, float z, int li, unsigned long 
     } else if (MODE == kRasterColor) {
         if (z < 1.0f) atomicMin(&tile[li], ((unsigned long long)f2u(z) << 32) | (unsigned long long)r.id);
     } else {
-        if (reinterpret_cast<const uint32_t*>(tile)[2 * li] == 0u) return;
+        const unsigned long long w = tile[li];
+        const uint32_t slot1 = (uint32_t)w;
         // a fragment drawn after the front-most one failed the depth test against it
-        if (r.id > tile32[li]) return;
-#if defined(WR_ABLATE) && (WR_ABLATE & 8)
-        unsigned long long old = tile[li];
-#else
-        unsigned long long old = atomicAdd(&tile[li], 1ull << 32);
-#endif
-        uint32_t c = (uint32_t)(old >> 32);
-#if defined(WR_ABLATE) && (WR_ABLATE & 4)
-        if (c == 77u)
-#endif
-        if (c < (uint32_t)kReplayK) ls.lists[(size_t)c * ls.cap + ((uint32_t)old - 1u)] = make_uint2(r.id, f2u(z));
+        if (slot1 == 0u || r.id > (uint32_t)(w >> 32)) return;
+        const uint32_t c = atomicAdd(&tile32[li], 1u);
+        if (c < (uint32_t)kReplayK) ls.lists[(size_t)c * ls.cap + (slot1 - 1u)] = make_uint2(r.id, f2u(z));
     }
 }
 
@@ -494,7 +488,7 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
                                                     int tile_rank, int tile_world, LayerSink ls) {
     constexpr int kRasterThreads = THREADS;
     __shared__ unsigned long long tile[MODE == kRasterShadow ? 1 : kBin * kBin];
-    __shared__ uint32_t tile32[MODE == kRasterColor ? 1 : kBin * kBin];  // layers: id of the front-most fragment
+    __shared__ uint32_t tile32[MODE == kRasterColor ? 1 : kBin * kBin];  // layers: fragments appended so far
     __shared__ uint32_t bigq[kRasterThreads];  // record indices of the chunk's large triangles
     __shared__ uint32_t s_nbig;
     __shared__ unsigned long long s_fmask;  // layers: bit (8*by + bx) set = 8x8 block holds a flagged pixel
@@ -517,8 +511,9 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
             // a wavefront holds one 64-pixel row of the bin
             int px = ox + (i & (kBin - 1)), py = oy + (i / kBin);
             uint32_t slot = (px < W && py < H) ? ls.rp_slot[(size_t)py * W + px] : 0u;
-            tile[tile_index(i & (kBin - 1), i / kBin)] = (unsigned long long)slot;
-            tile32[tile_index(i & (kBin - 1), i / kBin)] = slot ? ls.vis[(size_t)py * W + px] : 0u;
+            const uint32_t front = slot ? ls.vis[(size_t)py * W + px] : 0u;
+            tile[tile_index(i & (kBin - 1), i / kBin)] = ((unsigned long long)front << 32) | slot;
+            tile32[tile_index(i & (kBin - 1), i / kBin)] = 0u;
             unsigned long long m = __ballot(slot != 0u);
             m |= m >> 4; m |= m >> 2; m |= m >> 1;
             m &= 0x0101010101010101ull;
@@ -652,8 +647,8 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
         if (MODE == kRasterShadow) {
             depth[o] = u2f(tile32[ti]);
         } else if (MODE == kRasterLayers) {
-            unsigned long long k = tile[ti];
-            if ((uint32_t)k != 0u) ls.list_count[(uint32_t)k - 1u] = (uint32_t)(k >> 32);
+            const uint32_t slot1 = (uint32_t)tile[ti];
+            if (slot1 != 0u) ls.list_count[slot1 - 1u] = tile32[ti];
         } else {
             unsigned long long k = tile[ti];
             vis[o] = (uint32_t)k;
