@@ -39,6 +39,10 @@ import numpy as np  # noqa: E402
 FLOP_PER_FOG_NOISE_EVAL = 5198
 PEAK_FP32_TFLOPS = 157.3   # MI355X f32 vector peak = dense f32 matrix peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
+# HBM bytes of one k_fog_march launch on the default frame, from the rocprofv3 PMC passes kept
+# in profiles/ (FETCH_SIZE doubled as the gfx950 note prescribes, plus WRITE_SIZE); None until
+# such a pass has been recorded for the current kernel.
+FOG_MARCH_HBM_BYTES = None
 
 
 def build_scene(args):
@@ -198,20 +202,23 @@ def main():
     total_frames = args.steps * world * frames_per_step
     fps = total_frames / dt
 
+    default_frame = (args.workload == "frame" and (W, H, S) == (1920, 1080, 2048) and args.detail == 1.0
+                     and args.tex_size == 1024 and not args.sponza)
     out = None
     if rank == 0:
-        fog_s = st.ms_fog * 1e-3
+        # the dominant kernel: k_fog_march, bracketed by its own HIP events on its stream
+        fog_s = st.ms_fog_march * 1e-3
         fog_flops = FLOP_PER_FOG_NOISE_EVAL * noise_evals
         frame_bytes = algorithmic_bytes(sc, W, H, S, shaded, fog_frags)
         roofline = {
-            "kernel": "k_fog (fog.wgsl fragment stage: ray march through 8-octave value noise)",
+            "kernel": "k_fog_march (fog.wgsl fragment stage: two ray marches through 2 x 8 octaves of value noise)",
             "bound": "valu",
             "achieved": (fog_flops / fog_s) / 1e12 if fog_s > 0 else None,
             "peak": PEAK_FP32_TFLOPS,
             "unit": "TFLOP/s",
             "frac": ((fog_flops / fog_s) / 1e12) / PEAK_FP32_TFLOPS if fog_s > 0 else None,
-            "traffic": None,
-            "launch_ms": st.ms_fog,
+            "traffic": FOG_MARCH_HBM_BYTES if default_frame else None,
+            "launch_ms": st.ms_fog_march,
             "launches_averaged": int(st.profiled_frames),
             "flop_per_launch": fog_flops,
         }

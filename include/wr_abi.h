@@ -123,10 +123,13 @@ typedef struct WrConfig {
 
 typedef struct WrContext WrContext;
 
-/* Per-stage device times and per-frame counters.  Times are HIP-event milliseconds on the
- * context's stream, averaged over the (at most 128 most recent) frames rendered since
- * wr_set_profiling(ctx, 1); counters are those of the last frame.  No counterpart in the reference
- * (timestamp_writes: None on every pass, state.rs:660,713,749,788). */
+/* Per-stage device times and per-frame counters.  Times are HIP-event milliseconds, averaged
+ * over the (at most 128 most recent) frames rendered since wr_set_profiling(ctx, 1); counters
+ * are those of the last frame.  The shadow pass runs on a library-owned side stream next to
+ * the geometry pass, so ms_shadow and ms_geometry overlap, ms_shade includes any wait for the
+ * shadow maps, and ms_total is the frame from first to last kernel, not the sum.  No
+ * counterpart in the reference (timestamp_writes: None on every pass,
+ * state.rs:660,713,749,788). */
 typedef struct WrFrameStats {
     float ms_shadow;   /* shadow vertex + setup + binning + raster, six faces */
     float ms_geometry; /* geometry vertex + setup + binning + raster */
@@ -141,6 +144,8 @@ typedef struct WrFrameStats {
     uint64_t shaded_fragments;   /* PBS fragments shaded (counting mode only) */
     uint64_t replay_pixels;      /* pixels that took the ordered-blend path (counting mode only) */
     uint64_t replay_slow_pixels; /* of those, pixels covered by too many fragments for the fast path */
+    float ms_fog_march;          /* the fog march kernel alone (part of ms_fog) */
+    uint32_t reserved;
 } WrFrameStats;
 
 /* ------------------------------------------------------------------ context */

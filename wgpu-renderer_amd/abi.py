@@ -90,6 +90,8 @@ class FrameStats(C.Structure):
         ("shaded_fragments", C.c_uint64),
         ("replay_pixels", C.c_uint64),
         ("replay_slow_pixels", C.c_uint64),
+        ("ms_fog_march", C.c_float),
+        ("reserved", C.c_uint32),
     ]
 
 

@@ -104,7 +104,7 @@ struct WrContext {
     // Profiling keeps one set of five stage-boundary events per frame in a ring; wr_get_stats
     // averages the stage times over the frames recorded since profiling was switched on.
     static constexpr int kEvFrames = 128;
-    static constexpr int kEvPerFrame = 6;  // frame start | shadow start, end (side stream) | geometry, shade, fog end
+    static constexpr int kEvPerFrame = 7;  // frame start | shadow start, end (side stream) | geometry, shade, fog end | march start
     hipEvent_t ev[kEvFrames][kEvPerFrame] = {};
     int ev_count = 0;  // frames recorded since wr_set_profiling(1), saturates at kEvFrames
     int ev_next = 0;
@@ -133,6 +133,7 @@ void dfree(T*& p) {
 
 void free_ws(WsAlloc& w) {
     dfree(w.ws.recs); dfree(w.ws.bb); dfree(w.ws.betas); dfree(w.counters); dfree(w.ws.bin_offset); dfree(w.ws.bin_items);
+    dfree(w.ws.clip_queue);
     w = WsAlloc();
 }
 
@@ -147,11 +148,13 @@ int alloc_ws(WrContext* ctx, WsAlloc& w, uint32_t slots, uint32_t ovf_cap, uint3
     WR_HIP(hipMalloc(&ws.recs, sizeof(Rec) * (size_t)layers * ((size_t)slots + ovf_cap)));
     WR_HIP(hipMalloc(&ws.bb, sizeof(uint2) * (size_t)layers * ((size_t)slots + ovf_cap)));
     WR_HIP(hipMalloc(&ws.betas, sizeof(float) * 9 * (size_t)layers * ovf_cap + 64));
-    w.counters_bytes = sizeof(uint32_t) * ((size_t)layers + 2 * nb + extra_counters);
+    w.counters_bytes = sizeof(uint32_t) * (2 * (size_t)layers + 2 * nb + extra_counters);
     WR_HIP(hipMalloc(&w.counters, w.counters_bytes));
     ws.ovf_count = w.counters;
     ws.bin_count = w.counters + layers;
     ws.bin_cursor = ws.bin_count + nb;
+    ws.clip_count = ws.bin_cursor + nb;
+    WR_HIP(hipMalloc(&ws.clip_queue, sizeof(uint32_t) * (size_t)layers * slots));
     WR_HIP(hipMalloc(&ws.bin_offset, sizeof(uint32_t) * (nb + 1)));
     WR_HIP(hipMalloc(&ws.bin_items, sizeof(uint32_t) * ((size_t)items_cap + 1)));
     WR_HIP(hipMemset(w.counters, 0, w.counters_bytes));
@@ -370,6 +373,8 @@ int shadow_stage(WrContext* ctx, hipStream_t st, const FrameConsts& fc) {
     hipLaunchKernelGGL(k_vs_shadow, grid1(g.nv, 6), dim3(256), 0, st, g.pos, g.nv, ctx->d_shadow_clip, fc);
     hipLaunchKernelGGL(k_setup<true>, grid1(g.ntris, 6), dim3(256), 0, st, ctx->d_shadow_clip, g.nv, g.idx, g.ntris,
                        ctx->shadow.ws, ctx->S, ctx->S, 0, 1);
+    hipLaunchKernelGGL(k_setup_clip<true>, dim3(128, 6, 1), dim3(64), 0, st, ctx->d_shadow_clip, g.nv, g.idx, ctx->shadow.ws,
+                       ctx->S, ctx->S, 0, 1);
     return bin_and_raster(ctx, st, ctx->shadow, true, 0, 1);
 }
 
@@ -449,6 +454,8 @@ int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do
     hipLaunchKernelGGL(k_vs_geometry, grid1(g.nv), dim3(256), 0, ctx->stream, vin, ctx->vout, fc);
     hipLaunchKernelGGL(k_setup<false>, grid1(g.ntris, 1), dim3(256), 0, ctx->stream, ctx->vout.clip, g.nv, g.idx, g.ntris,
                        ctx->geom.ws, ctx->W, ctx->H, fc.tile_rank, fc.tile_world);
+    hipLaunchKernelGGL(k_setup_clip<false>, dim3(256, 1, 1), dim3(64), 0, ctx->stream, ctx->vout.clip, g.nv, g.idx, ctx->geom.ws,
+                       ctx->W, ctx->H, fc.tile_rank, fc.tile_world);
     if (lm.ntris)
         hipLaunchKernelGGL(k_setup_small, grid1(lm.ntris), dim3(256), 0, ctx->stream, lm.pos, lm.idx, lm.ntris, 0,
                            (passes & WR_PASS_LIGHT_DEBUG) ? 1 : 0, g.ntris, ctx->geom.ws, fc);
@@ -493,11 +500,15 @@ int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do
         dim3 fg((uint32_t)(ctx->W + kFogBlock - 1) / kFogBlock, (uint32_t)(ctx->H + kFogBlock - 1) / kFogBlock, 1);
         if (ctx->counting) {
             hipLaunchKernelGGL(k_fog_setup<true>, fg, dim3(1024), 0, ctx->stream, fa);
+            if (prof) WR_HIP(hipEventRecord(ev[6], ctx->stream));
             hipLaunchKernelGGL(k_fog_march<true>, mg, dim3(64), 0, ctx->stream, fa);
         } else {
             hipLaunchKernelGGL(k_fog_setup<false>, fg, dim3(1024), 0, ctx->stream, fa);
+            if (prof) WR_HIP(hipEventRecord(ev[6], ctx->stream));
             hipLaunchKernelGGL(k_fog_march<false>, mg, dim3(64), 0, ctx->stream, fa);
         }
+    } else if (prof) {
+        WR_HIP(hipEventRecord(ev[6], ctx->stream));
     }
     if (prof) {
         WR_HIP(hipEventRecord(ev[5], ctx->stream));
@@ -772,18 +783,19 @@ int wr_get_stats(WrContext* ctx, WrFrameStats* out) {
     if (rc != WR_OK) return rc;
     if (ctx->ev_count > 0) {
         // shadow runs on the side stream next to geometry; shade includes any wait for it
-        const int a[5] = {1, 0, 3, 4, 0}, b[5] = {2, 3, 4, 5, 5};  // shadow, geometry, shade, fog, frame
-        double ms[5] = {0, 0, 0, 0, 0};
+        const int a[6] = {1, 0, 3, 4, 0, 6}, b[6] = {2, 3, 4, 5, 5, 5};  // shadow, geometry, shade, fog, frame, march
+        double ms[6] = {0, 0, 0, 0, 0, 0};
         for (int f = 0; f < ctx->ev_count; ++f)
-            for (int i = 0; i < 5; ++i) {
+            for (int i = 0; i < 6; ++i) {
                 float t = 0.0f;
                 WR_HIP(hipEventElapsedTime(&t, ctx->ev[f][a[i]], ctx->ev[f][b[i]]));
                 ms[i] += t;
             }
-        for (int i = 0; i < 5; ++i) ms[i] /= ctx->ev_count;
+        for (int i = 0; i < 6; ++i) ms[i] /= ctx->ev_count;
         ctx->stats.ms_shadow = (float)ms[0]; ctx->stats.ms_geometry = (float)ms[1];
         ctx->stats.ms_shade = (float)ms[2]; ctx->stats.ms_fog = (float)ms[3];
         ctx->stats.ms_total = (float)ms[4];
+        ctx->stats.ms_fog_march = (float)ms[5];
         ctx->stats.profiled_frames = (uint32_t)ctx->ev_count;
     }
     unsigned long long c[8];

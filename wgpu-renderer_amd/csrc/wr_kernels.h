@@ -23,7 +23,7 @@ namespace wr {
 
 struct RasterWS {
     Rec* recs;            // [layers][slots + ovf_cap]
-    uint2* bb;            // [layers][slots + ovf_cap] pixel bounding box of each record, or kBBInvalid
+    uint2* bb;            // [layers][slots + ovf_cap] pixel bounding box of each record, or (kBBInvalid, kBB*)
     float* betas;         // [layers][ovf_cap][9] clip weights of records born in the clipper
     uint32_t* ovf_count;  // [layers]
     uint32_t* bin_count;  // [layers * bins]
@@ -32,6 +32,8 @@ struct RasterWS {
     uint32_t* bin_items;  // record indices, grouped by bin
     uint32_t* total_items;
     uint32_t* err;
+    uint32_t* clip_count; // [layers] triangles queued for the clipper this frame
+    uint32_t* clip_queue; // [layers][slots] their triangle indices
     uint32_t slots, ovf_cap, items_cap;
     int bins_x, bins_y, layers;
 };
@@ -101,7 +103,12 @@ __device__ inline Rec load_rec(const Rec* src) {
     return r;
 }
 
+// bb.x == kBBInvalid: the slot holds no raster record; bb.y then says whether its Rec is the
+// parent of clipped fan triangles (first index, count) or nothing at all.  A slot without a
+// record is marked here only: its 64-byte Rec is not touched (a 4-byte store into it costs a
+// whole line of HBM write traffic, six faces x every culled triangle per frame).
 constexpr uint32_t kBBInvalid = 0xFFFFFFFFu;
+constexpr uint32_t kBBNothing = 0u, kBBClippedParent = 1u;
 
 // Adds 1 to counters[key] for every lane with `active`, with one atomic per distinct key in
 // the wavefront (ballot + leader), and returns to each such lane the value its own
@@ -239,9 +246,7 @@ __device__ __attribute__((noinline)) void emit_clipped(const V4* c, uint32_t tri
                         }
                     }
                 } else {
-                    r.id = kRecInvalid;
-                    store_rec(&tg.recs[ri], r);
-                    tg.bb[ri] = make_uint2(kBBInvalid, 0u);
+                    tg.bb[ri] = make_uint2(kBBInvalid, kBBNothing);
                 }
             }
             parent.id = kRecClippedParent;
@@ -249,23 +254,27 @@ __device__ __attribute__((noinline)) void emit_clipped(const V4* c, uint32_t tri
             parent.Y0 = (int32_t)nf;
         }
     }
-    store_rec(&tg.recs[slot], parent);
-    tg.bb[slot] = make_uint2(kBBInvalid, 0u);
+    if (parent.id == kRecClippedParent) store_rec(&tg.recs[slot], parent);
+    tg.bb[slot] = make_uint2(kBBInvalid, parent.id == kRecClippedParent ? kBBClippedParent : kBBNothing);
 }
 
 // Sets up one triangle, stores its record (only if something can be covered), its bounding
 // box, and counts it into the bins it touches.  `have` is false for lanes past the end of
 // the triangle list; they still take part in the wave-aggregated counting.
-template <bool SHADOW>
-__device__ inline void emit_triangle(bool have, const V4* c, uint32_t tri, uint32_t slot, const RasterWS& ws,
+// With DEFER_CLIP a triangle that needs the clipper is left alone and reported to the caller
+// (return value), which queues it for k_setup_clip: the clipper's arrays and registers then
+// do not weigh on the occupancy of the kernel that sets up the other 99 %.
+template <bool SHADOW, bool DEFER_CLIP>
+__device__ inline bool emit_triangle(bool have, const V4* c, uint32_t tri, uint32_t slot, const RasterWS& ws,
                                      const SetupTarget& tg) {
     Rec r;
     r.id = kRecInvalid;
-    bool valid = false;
+    bool valid = false, deferred = false;
     if (have) {
         int cls = classify_triangle(c);
         if (cls == 2) {
-            emit_clipped<SHADOW>(c, tri, slot, ws, tg);
+            if (DEFER_CLIP) deferred = true;
+            else emit_clipped<SHADOW>(c, tri, slot, ws, tg);
         } else {
             if (cls == 1) {
                 ClipVert cv[3];
@@ -276,17 +285,17 @@ __device__ inline void emit_triangle(bool have, const V4* c, uint32_t tri, uint3
                 store_rec(&tg.recs[slot], r);
                 tg.bb[slot] = make_uint2(r.bbmin, r.bbmax);
             } else {
-                tg.recs[slot].id = kRecInvalid;
-                tg.bb[slot] = make_uint2(kBBInvalid, 0u);
+                tg.bb[slot] = make_uint2(kBBInvalid, kBBNothing);
             }
         }
     }
-    if (!tg.count) return;
+    if (!tg.count) return deferred;
     int b = 0;
     const bool single = valid && bb_single_bin(r.bbmin, r.bbmax, ws.bins_x, b);
     const uint32_t gb = tg.layer * (uint32_t)(ws.bins_x * ws.bins_y) + (uint32_t)b;
     wave_agg_inc(ws.bin_count, single && bin_owned(b, tg.tile_rank, tg.tile_world), gb);
     if (valid && !single) bin_record_multi<false>(ws, tg.layer, slot, r, tg.tile_rank, tg.tile_world);
+    return deferred;
 }
 
 __device__ inline SetupTarget setup_target(const RasterWS& ws, uint32_t layer, int W, int H, int tile_rank, int tile_world) {
@@ -316,8 +325,32 @@ __global__ __launch_bounds__(256) void k_setup(const float4* clip, uint32_t nv, 
             float4 v = cl[idx[3 * t + k]];
             c[k] = V4{v.x, v.y, v.z, v.w};
         }
+    __shared__ uint32_t s_cnt, s_base;
     SetupTarget tg = setup_target(ws, layer, W, H, tile_rank, tile_world);
-    emit_triangle<SHADOW>(have, c, t, t, ws, tg);
+    const bool deferred = emit_triangle<SHADOW, true>(have, c, t, t, ws, tg);
+    if (!__syncthreads_or(deferred ? 1 : 0)) return;
+    const uint32_t k = group_append(&ws.clip_count[layer], deferred ? 1u : 0u, &s_cnt, &s_base);
+    if (deferred) ws.clip_queue[(size_t)layer * ws.slots + k] = t;
+}
+
+// The triangles k_setup queued: clipped against the near, far and guard-band planes, their fan
+// triangles set up and counted into the bins.
+template <bool SHADOW>
+__global__ __launch_bounds__(64) void k_setup_clip(const float4* clip, uint32_t nv, const uint32_t* idx, RasterWS ws, int W, int H,
+                                                   int tile_rank, int tile_world) {
+    const uint32_t layer = blockIdx.y;
+    const uint32_t n = min(ws.clip_count[layer], ws.slots);
+    const float4* cl = clip + (size_t)layer * nv;
+    SetupTarget tg = setup_target(ws, layer, W, H, tile_rank, tile_world);
+    for (uint32_t k = blockIdx.x * 64u + threadIdx.x; k < n; k += gridDim.x * 64u) {
+        const uint32_t t = ws.clip_queue[(size_t)layer * ws.slots + k];
+        V4 c[3];
+        for (int j = 0; j < 3; ++j) {
+            float4 v = cl[idx[3 * t + j]];
+            c[j] = V4{v.x, v.y, v.z, v.w};
+        }
+        emit_clipped<SHADOW>(c, t, t, ws, tg);
+    }
 }
 
 // The two 12-triangle helper models.  mode 0: light marker (light_debug.wgsl:12-21), its
@@ -328,8 +361,7 @@ __global__ void k_setup_small(const float4* pos, const uint32_t* idx, uint32_t n
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const bool have = t < ntris && enabled;
     if (t < ntris && !enabled) {
-        ws.recs[slot_base + t].id = kRecInvalid;
-        ws.bb[slot_base + t] = make_uint2(kBBInvalid, 0u);
+        ws.bb[slot_base + t] = make_uint2(kBBInvalid, kBBNothing);
     }
     V4 c[3];
     if (have)
@@ -342,7 +374,7 @@ __global__ void k_setup_small(const float4* pos, const uint32_t* idx, uint32_t n
         }
     SetupTarget tg = setup_target(ws, 0, fc.W, fc.H, fc.tile_rank, fc.tile_world);
     tg.count = mode == 0;
-    emit_triangle<false>(have, c, slot_base + t, slot_base + t, ws, tg);
+    emit_triangle<false, false>(have, c, slot_base + t, slot_base + t, ws, tg);
 }
 
 // ------------------------------------------------------------------ binning
@@ -925,6 +957,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(64) void k_replay_slow(ShadeArgs a) {
     const BlendWS& bw = a.bw;
     const uint32_t n = min(bw.counts[2], bw.cap);
+    if (blockIdx.x * 64u >= n) return;
     for (uint32_t k = blockIdx.x * 64u + threadIdx.x; k < n; k += gridDim.x * 64u) {
         const uint32_t pi = bw.slot_pixel[bw.slow_slots[k]];
         if (COUNT) atomicAdd(&a.counters[4], 1ull);
@@ -1071,8 +1104,9 @@ __global__ __launch_bounds__(1024) void k_fog_setup(FogArgs a) {
         __syncthreads();
         if (tid < 256 && c0 + tid < nrec) {
             const Rec* rp = &a.ws.recs[c0 + tid];
-            const uint32_t id = rp->id, bbmin = rp->bbmin, bbmax = rp->bbmax;
-            if (id < kRecClippedParent &&
+            const uint2 bb = a.ws.bb[c0 + tid];
+            const uint32_t bbmin = bb.x, bbmax = bb.y;
+            if (bbmin != kBBInvalid &&
                 !((int)(bbmin & 0xffffu) > bx1 || (int)(bbmax & 0xffffu) < bx0 || (int)(bbmin >> 16) > by1 || (int)(bbmax >> 16) < by0)) {
                 Rec r = load_rec(rp);
                 Edges e;
@@ -1129,14 +1163,17 @@ __global__ __launch_bounds__(1024) void k_fog_setup(FogArgs a) {
         ShadowMap sm{a.shadow, a.fc.S};
         uint32_t col = a.color[pi];
         for (uint32_t t = 0; t < a.ntris; ++t) {
-            Rec slot = load_rec(&a.ws.recs[t]);
-            if (slot.id == kRecInvalid) continue;
+            const uint2 sbb = a.ws.bb[t];
+            if (sbb.x == kBBInvalid && sbb.y != kBBClippedParent) continue;
             uint32_t first = t, count = 1;
-            if (slot.id == kRecClippedParent) { first = (uint32_t)slot.X0; count = (uint32_t)slot.Y0; }
+            if (sbb.x == kBBInvalid) {
+                Rec parent = load_rec(&a.ws.recs[t]);
+                first = (uint32_t)parent.X0; count = (uint32_t)parent.Y0;
+            }
             for (uint32_t s = 0; s < count; ++s) {
                 uint32_t ri = first + s;
-                Rec r = (slot.id == kRecClippedParent) ? load_rec(&a.ws.recs[ri]) : slot;
-                if (r.id >= kRecClippedParent) continue;
+                if (a.ws.bb[ri].x == kBBInvalid) continue;
+                Rec r = load_rec(&a.ws.recs[ri]);
                 if (px < (int)(r.bbmin & 0xffffu) || px > (int)(r.bbmax & 0xffffu) || py < (int)(r.bbmin >> 16) || py > (int)(r.bbmax >> 16)) continue;
                 const float* beta = ri >= a.ws.slots ? a.ws.betas + (size_t)(ri - a.ws.slots) * 9 : nullptr;
                 V3 o;
