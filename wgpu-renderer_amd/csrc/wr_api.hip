@@ -68,8 +68,8 @@ struct WrContext {
     int W = 0, H = 0, S = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    // The shadow pass and the fog pass's preparation depend only on the frame's uniforms, so
-    // they run on a side stream next to the geometry pass; the shading kernels wait for them.
+    // The shadow pass depends only on the frame's uniforms, so it runs on a side stream next to
+    // the geometry pass; the shading kernels wait for it.
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
@@ -369,7 +369,11 @@ int bin_and_raster(WrContext* ctx, hipStream_t st, WsAlloc& w, bool shadow, int 
 
 int shadow_stage(WrContext* ctx, hipStream_t st, const FrameConsts& fc) {
     const ModelDev& g = ctx->dev[WR_MODEL_GEOMETRY];
-    WR_HIP(hipMemsetAsync(ctx->shadow.counters, 0, ctx->shadow.counters_bytes, st));
+    {
+        ClearList cl{};
+        cl.ptr[0] = ctx->shadow.counters; cl.words[0] = (uint32_t)(ctx->shadow.counters_bytes / 4);
+        hipLaunchKernelGGL(k_clear_words, dim3(32), dim3(256), 0, st, cl);
+    }
     hipLaunchKernelGGL(k_vs_shadow, grid1(g.nv, 6), dim3(256), 0, st, g.pos, g.nv, ctx->d_shadow_clip, fc);
     hipLaunchKernelGGL(k_setup<true>, grid1(g.ntris, 6), dim3(256), 0, st, ctx->d_shadow_clip, g.nv, g.idx, g.ntris,
                        ctx->shadow.ws, ctx->S, ctx->S, 0, 1);
@@ -430,26 +434,23 @@ int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do
     const bool fog_pass = (passes & WR_PASS_FOG) && fm.ntris;
     FogArgs fa;
     memset(&fa, 0, sizeof(fa));
-    // side stream: shadow maps, fog volume set-up, noise tables
+    // side stream: shadow maps
     WR_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
     WR_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
     if (prof) WR_HIP(hipEventRecord(ev[1], ctx->side));
     if (do_shadow && (passes & WR_PASS_SHADOWS))
         if ((rc = shadow_stage(ctx, ctx->side, fc)) != WR_OK) return rc;
     if (prof) WR_HIP(hipEventRecord(ev[2], ctx->side));
-    if (fog_pass) {
-        WR_HIP(hipMemsetAsync(ctx->fog.counters, 0, ctx->fog.counters_bytes, ctx->side));
-        hipLaunchKernelGGL(k_setup_small, grid1(fm.ntris), dim3(256), 0, ctx->side, fm.pos, fm.idx, fm.ntris, 1, 1, 0u,
-                           ctx->fog.ws, fc);
-        uint32_t max_entries = 0;
-        fa.tables_noise = plan_noise_tables(ctx, fc, &max_entries);
-        if (max_entries)
-            hipLaunchKernelGGL(k_fog_tables, dim3((max_entries + 255u) / 256u, 16, 1), dim3(256), 0, ctx->side, fa.tables_noise);
-    }
     WR_HIP(hipEventRecord(ctx->ev_join, ctx->side));
 
     // geometry + light marker -> visibility / depth
-    WR_HIP(hipMemsetAsync(ctx->geom.counters, 0, ctx->geom.counters_bytes, ctx->stream));
+    {
+        ClearList cl{};
+        cl.ptr[0] = ctx->geom.counters; cl.words[0] = (uint32_t)(ctx->geom.counters_bytes / 4);
+        cl.ptr[1] = ctx->blend.counts; cl.words[1] = (uint32_t)(ctx->blend_clear_bytes / 4);
+        if (fog_pass) { cl.ptr[2] = ctx->fog.counters; cl.words[2] = (uint32_t)(ctx->fog.counters_bytes / 4); }
+        hipLaunchKernelGGL(k_clear_words, dim3(8), dim3(256), 0, ctx->stream, cl);
+    }
     VertexIn vin{g.pos, g.uv, g.nrm, g.tan, g.bit, g.nv};
     hipLaunchKernelGGL(k_vs_geometry, grid1(g.nv), dim3(256), 0, ctx->stream, vin, ctx->vout, fc);
     hipLaunchKernelGGL(k_setup<false>, grid1(g.ntris, 1), dim3(256), 0, ctx->stream, ctx->vout.clip, g.nv, g.idx, g.ntris,
@@ -461,6 +462,16 @@ int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do
                            (passes & WR_PASS_LIGHT_DEBUG) ? 1 : 0, g.ntris, ctx->geom.ws, fc);
     if ((rc = bin_and_raster(ctx, ctx->stream, ctx->geom, false, fc.tile_rank, fc.tile_world)) != WR_OK) return rc;
     if (prof) WR_HIP(hipEventRecord(ev[3], ctx->stream));
+    // fog volume set-up and noise tables: independent of everything above, placed where this
+    // stream would otherwise idle until the shadow maps are done
+    if (fog_pass) {
+        hipLaunchKernelGGL(k_setup_small, grid1(fm.ntris), dim3(256), 0, ctx->stream, fm.pos, fm.idx, fm.ntris, 1, 1, 0u,
+                           ctx->fog.ws, fc);
+        uint32_t max_entries = 0;
+        fa.tables_noise = plan_noise_tables(ctx, fc, &max_entries);
+        if (max_entries)
+            hipLaunchKernelGGL(k_fog_tables, dim3((max_entries + 255u) / 256u, 16, 1), dim3(256), 0, ctx->stream, fa.tables_noise);
+    }
     WR_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));  // shading reads the shadow maps
 
     ShadeArgs sa;
@@ -470,7 +481,6 @@ int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do
     sa.mats = ctx->d_mats; sa.tex = ctx->d_tex; sa.texels = ctx->d_texels; sa.tables = ctx->d_tables;
     sa.shadow = ctx->d_shadow; sa.counters = ctx->d_counters;
     sa.bw = ctx->blend;
-    WR_HIP(hipMemsetAsync(ctx->blend.counts, 0, ctx->blend_clear_bytes, ctx->stream));
     dim3 pg((uint32_t)(ctx->W + 15) / 16, (uint32_t)(ctx->H + 15) / 16, 1);
     if (ctx->counting) hipLaunchKernelGGL(k_shade<true>, pg, dim3(256), 0, ctx->stream, sa);
     else hipLaunchKernelGGL(k_shade<false>, pg, dim3(256), 0, ctx->stream, sa);

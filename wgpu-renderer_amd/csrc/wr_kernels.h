@@ -1243,6 +1243,13 @@ __global__ __launch_bounds__(256) void k_pack_bins(const uint32_t* color, uint32
     }
 }
 
+// Zeroes the per-frame counter blocks of one stream in a single launch.
+struct ClearList { uint32_t* ptr[4]; uint32_t words[4]; };
+__global__ __launch_bounds__(256) void k_clear_words(ClearList c) {
+    for (int k = 0; k < 4; ++k)
+        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < c.words[k]; i += gridDim.x * 256u) c.ptr[k][i] = 0u;
+}
+
 __global__ void k_fill_f32(float* p, size_t n, float v) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
