@@ -229,6 +229,28 @@ def test_ordered_blending_many_layers():
     assert g["counters"]["replay_pixels"] > g["counters"]["replay_slow_pixels"]
 
 
+def test_fog_volume_with_overlapping_parts(tiny_scene):
+    """A fog model that is not convex (a small slab floating above the box): pixels covered by
+    two fog fragments are marched and blended once per fragment, in draw order."""
+    w, h, s = 240, 135, 128
+    cube = scene.cube_model().meshes[0]
+    slab = cube.vertices.copy()
+    slab[:, 0:3] = slab[:, 0:3] * np.float32(0.4) + np.array([0.0, 1.8, 0.0], np.float32)
+    fog = scene.Model([cube, scene.Mesh(slab, cube.indices.copy(), 0)], [])
+    sc = scene.Scene(tiny_scene.textures, tiny_scene.geometry, fog, tiny_scene.marker,
+                     tiny_scene.geometry_instance, tiny_scene.fog_instance)
+    for pose in (((0.0, 900.0, 0.0), -80.0, 0.0), ((-900.0, 500.0, 100.0), -25.0, 0.0)):
+        cam, light, glob = default_inputs(w, h, pose=pose)
+        g = render_gpu(sc, cam, light, glob, abi.PASS_ALL, w, h, s, counting=True)
+        o = render_oracle(sc, cam, light, glob, abi.PASS_ALL, w, h, s, threads=4)
+        assert_parity(g, o)
+        assert np.array_equal(g["color"], o["color"])
+        assert g["counters"]["fog_fragments"] == o["counters"]["fog_fragments"] > 0
+        assert g["counters"]["fog_noise_evals"] == o["counters"]["fog_noise_evals"]
+    g1 = render_gpu(tiny_scene, cam, light, glob, abi.PASS_ALL, w, h, s, counting=True)
+    assert g["counters"]["fog_fragments"] > g1["counters"]["fog_fragments"]  # the slab added fragments
+
+
 def test_draw_orders_give_different_images():
     w, h, s = 160, 120, 64
     cam = abi.camera_uniform((0.0, 0.0, 500.0), 0.0, -90.0, 55.0, w, h)

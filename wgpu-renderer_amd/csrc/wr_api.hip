@@ -71,7 +71,7 @@ struct WrContext {
     // The shadow pass depends only on the frame's uniforms, so it runs on a side stream next to
     // the geometry pass; the shading kernels wait for it.
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_shadow_done = nullptr, ev_geom_done = nullptr;
     std::string err;
 
     ModelHost host[3];
@@ -98,13 +98,15 @@ struct WrContext {
     float fog_aabb[6] = {0, 0, 0, 0, 0, 0};  // fog model bounds in model space (min xyz, max xyz)
     uint32_t* d_fog_pixel = nullptr; // [W*H] fog march work items: pixel index
     float4* d_fog_ray = nullptr;     // [W*H] ray origin + max_fog_depth
+    float4* d_fog_src = nullptr;     // [W*H] marched fog colour of each item
+    uint32_t* d_fog_multi = nullptr; // [W*H] pixels with several fog fragments
     uint32_t* d_err = nullptr;  // [0] error bits, [1] geometry bin items, [2] shadow bin items, [3] fog (unused)
 
     bool profiling = false, counting = false;
     // Profiling keeps one set of five stage-boundary events per frame in a ring; wr_get_stats
     // averages the stage times over the frames recorded since profiling was switched on.
     static constexpr int kEvFrames = 128;
-    static constexpr int kEvPerFrame = 7;  // frame start | shadow start, end (side stream) | geometry, shade, fog end | march start
+    static constexpr int kEvPerFrame = 9;  // see frame_stages
     hipEvent_t ev[kEvFrames][kEvPerFrame] = {};
     int ev_count = 0;  // frames recorded since wr_set_profiling(1), saturates at kEvFrames
     int ev_next = 0;
@@ -162,7 +164,7 @@ int alloc_ws(WrContext* ctx, WsAlloc& w, uint32_t slots, uint32_t ovf_cap, uint3
 }
 
 void free_targets(WrContext* c) {
-    dfree(c->d_vis); dfree(c->d_depth); dfree(c->d_color); dfree(c->d_fog_pixel); dfree(c->d_fog_ray);
+    dfree(c->d_vis); dfree(c->d_depth); dfree(c->d_color); dfree(c->d_fog_pixel); dfree(c->d_fog_ray); dfree(c->d_fog_src); dfree(c->d_fog_multi);
     BlendWS& b = c->blend;
     dfree(b.rp_slot); dfree(b.slot_pixel); dfree(b.counts); dfree(b.lists); dfree(b.list_count);
     dfree(b.slow_slots); dfree(b.slot_frags); dfree(b.frag_item); dfree(b.frag_src);
@@ -206,6 +208,8 @@ int alloc_targets(WrContext* ctx) {
     WR_HIP(hipMemset(b.rp_slot, 0, n * 4));
     WR_HIP(hipMalloc(&ctx->d_fog_pixel, n * 4));
     WR_HIP(hipMalloc(&ctx->d_fog_ray, n * sizeof(float4)));
+    WR_HIP(hipMalloc(&ctx->d_fog_src, n * sizeof(float4)));
+    WR_HIP(hipMalloc(&ctx->d_fog_multi, n * 4));
     WR_HIP(hipMemset(ctx->d_color, 0, n * 4));
     return WR_OK;
 }
@@ -423,57 +427,87 @@ NoiseTables plan_noise_tables(const WrContext* ctx, const FrameConsts& fc, uint3
     return nt;
 }
 
+// One frame.  Main stream: geometry pass, shading, fog blend.  Side stream: shadow pass, then
+// (once the geometry depth exists) the fog pass up to and including the march, which reads
+// depth and shadow maps but not the colour, next to the shading kernels.
+// Profiling events of a frame: [0] frame start, [3] geometry end, [4] shade end, [7] frame end
+// on the main stream; [1] shadow start, [2] shadow end, [8] fog start, [6] march start,
+// [5] march end on the side stream.
 int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do_shadow) {
     const ModelDev& g = ctx->dev[WR_MODEL_GEOMETRY];
     const ModelDev& lm = ctx->dev[WR_MODEL_LIGHT_MARKER];
     const ModelDev& fm = ctx->dev[WR_MODEL_FOG_VOLUME];
     const bool prof = ctx->profiling;
     hipEvent_t* ev = ctx->ev[ctx->ev_next];
+    hipStream_t ms = ctx->stream, ss = ctx->side;
     int rc;
-    if (prof) WR_HIP(hipEventRecord(ev[0], ctx->stream));
+    if (prof) WR_HIP(hipEventRecord(ev[0], ms));
     const bool fog_pass = (passes & WR_PASS_FOG) && fm.ntris;
-    FogArgs fa;
-    memset(&fa, 0, sizeof(fa));
-    // side stream: shadow maps
-    WR_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
-    WR_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
-    if (prof) WR_HIP(hipEventRecord(ev[1], ctx->side));
-    if (do_shadow && (passes & WR_PASS_SHADOWS))
-        if ((rc = shadow_stage(ctx, ctx->side, fc)) != WR_OK) return rc;
-    if (prof) WR_HIP(hipEventRecord(ev[2], ctx->side));
-    WR_HIP(hipEventRecord(ctx->ev_join, ctx->side));
 
-    // geometry + light marker -> visibility / depth
+    // side stream: shadow maps
+    WR_HIP(hipEventRecord(ctx->ev_fork, ms));
+    WR_HIP(hipStreamWaitEvent(ss, ctx->ev_fork, 0));
+    if (prof) WR_HIP(hipEventRecord(ev[1], ss));
+    if (do_shadow && (passes & WR_PASS_SHADOWS))
+        if ((rc = shadow_stage(ctx, ss, fc)) != WR_OK) return rc;
+    if (prof) WR_HIP(hipEventRecord(ev[2], ss));
+    WR_HIP(hipEventRecord(ctx->ev_shadow_done, ss));
+
+    // main stream: geometry + light marker -> visibility / depth
     {
         ClearList cl{};
         cl.ptr[0] = ctx->geom.counters; cl.words[0] = (uint32_t)(ctx->geom.counters_bytes / 4);
         cl.ptr[1] = ctx->blend.counts; cl.words[1] = (uint32_t)(ctx->blend_clear_bytes / 4);
         if (fog_pass) { cl.ptr[2] = ctx->fog.counters; cl.words[2] = (uint32_t)(ctx->fog.counters_bytes / 4); }
-        hipLaunchKernelGGL(k_clear_words, dim3(8), dim3(256), 0, ctx->stream, cl);
+        hipLaunchKernelGGL(k_clear_words, dim3(8), dim3(256), 0, ms, cl);
     }
     VertexIn vin{g.pos, g.uv, g.nrm, g.tan, g.bit, g.nv};
-    hipLaunchKernelGGL(k_vs_geometry, grid1(g.nv), dim3(256), 0, ctx->stream, vin, ctx->vout, fc);
-    hipLaunchKernelGGL(k_setup<false>, grid1(g.ntris, 1), dim3(256), 0, ctx->stream, ctx->vout.clip, g.nv, g.idx, g.ntris,
+    hipLaunchKernelGGL(k_vs_geometry, grid1(g.nv), dim3(256), 0, ms, vin, ctx->vout, fc);
+    hipLaunchKernelGGL(k_setup<false>, grid1(g.ntris, 1), dim3(256), 0, ms, ctx->vout.clip, g.nv, g.idx, g.ntris,
                        ctx->geom.ws, ctx->W, ctx->H, fc.tile_rank, fc.tile_world);
-    hipLaunchKernelGGL(k_setup_clip<false>, dim3(256, 1, 1), dim3(64), 0, ctx->stream, ctx->vout.clip, g.nv, g.idx, ctx->geom.ws,
+    hipLaunchKernelGGL(k_setup_clip<false>, dim3(256, 1, 1), dim3(64), 0, ms, ctx->vout.clip, g.nv, g.idx, ctx->geom.ws,
                        ctx->W, ctx->H, fc.tile_rank, fc.tile_world);
     if (lm.ntris)
-        hipLaunchKernelGGL(k_setup_small, grid1(lm.ntris), dim3(256), 0, ctx->stream, lm.pos, lm.idx, lm.ntris, 0,
+        hipLaunchKernelGGL(k_setup_small, grid1(lm.ntris), dim3(256), 0, ms, lm.pos, lm.idx, lm.ntris, 0,
                            (passes & WR_PASS_LIGHT_DEBUG) ? 1 : 0, g.ntris, ctx->geom.ws, fc);
-    if ((rc = bin_and_raster(ctx, ctx->stream, ctx->geom, false, fc.tile_rank, fc.tile_world)) != WR_OK) return rc;
-    if (prof) WR_HIP(hipEventRecord(ev[3], ctx->stream));
-    // fog volume set-up and noise tables: independent of everything above, placed where this
-    // stream would otherwise idle until the shadow maps are done
+    if ((rc = bin_and_raster(ctx, ms, ctx->geom, false, fc.tile_rank, fc.tile_world)) != WR_OK) return rc;
+    if (prof) WR_HIP(hipEventRecord(ev[3], ms));
+    WR_HIP(hipEventRecord(ctx->ev_geom_done, ms));
+
+    // side stream: fog volume set-up, noise tables, fog raster, march
+    FogArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    WR_HIP(hipStreamWaitEvent(ss, ctx->ev_geom_done, 0));
+    if (prof) WR_HIP(hipEventRecord(ev[8], ss));
     if (fog_pass) {
-        hipLaunchKernelGGL(k_setup_small, grid1(fm.ntris), dim3(256), 0, ctx->stream, fm.pos, fm.idx, fm.ntris, 1, 1, 0u,
-                           ctx->fog.ws, fc);
+        hipLaunchKernelGGL(k_setup_small, grid1(fm.ntris), dim3(256), 0, ss, fm.pos, fm.idx, fm.ntris, 1, 1, 0u, ctx->fog.ws, fc);
         uint32_t max_entries = 0;
         fa.tables_noise = plan_noise_tables(ctx, fc, &max_entries);
         if (max_entries)
-            hipLaunchKernelGGL(k_fog_tables, dim3((max_entries + 255u) / 256u, 16, 1), dim3(256), 0, ctx->stream, fa.tables_noise);
+            hipLaunchKernelGGL(k_fog_tables, dim3((max_entries + 255u) / 256u, 16, 1), dim3(256), 0, ss, fa.tables_noise);
+        fa.fc = fc; fa.ws = ctx->fog.ws; fa.pos = fm.pos; fa.idx = fm.idx; fa.ntris = fm.ntris;
+        fa.depth = ctx->d_depth; fa.color = ctx->d_color; fa.shadow = ctx->d_shadow; fa.tables = ctx->d_tables;
+        fa.counters = ctx->d_counters;
+        // the fog workspace has one bin and is not binned, so its bin_count and bin_cursor words
+        // are free: they count the march items and the pixels with several fog fragments
+        fa.item_count = ctx->fog.ws.bin_count; fa.item_pixel = ctx->d_fog_pixel; fa.item_ray = ctx->d_fog_ray;
+        fa.item_src = ctx->d_fog_src;
+        fa.multi_count = ctx->fog.ws.bin_cursor; fa.multi_pixel = ctx->d_fog_multi;
+        dim3 mg((uint32_t)(((size_t)ctx->W * ctx->H + 63) / 64), 1, 1);
+        dim3 fg((uint32_t)(ctx->W + kFogBlock - 1) / kFogBlock, (uint32_t)(ctx->H + kFogBlock - 1) / kFogBlock, 1);
+        if (ctx->counting) hipLaunchKernelGGL(k_fog_setup<true>, fg, dim3(1024), 0, ss, fa);
+        else hipLaunchKernelGGL(k_fog_setup<false>, fg, dim3(1024), 0, ss, fa);
+        if (prof) WR_HIP(hipEventRecord(ev[6], ss));
+        if (ctx->counting) hipLaunchKernelGGL(k_fog_march<true>, mg, dim3(64), 0, ss, fa);
+        else hipLaunchKernelGGL(k_fog_march<false>, mg, dim3(64), 0, ss, fa);
+    } else if (prof) {
+        WR_HIP(hipEventRecord(ev[6], ss));
     }
-    WR_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));  // shading reads the shadow maps
+    if (prof) WR_HIP(hipEventRecord(ev[5], ss));
+    WR_HIP(hipEventRecord(ctx->ev_join, ss));
 
+    // main stream: shading (reads the shadow maps)
+    WR_HIP(hipStreamWaitEvent(ms, ctx->ev_shadow_done, 0));
     ShadeArgs sa;
     sa.fc = fc; sa.ws = ctx->geom.ws; sa.vis = ctx->d_vis; sa.depth = ctx->d_depth; sa.color = ctx->d_color;
     sa.idx = g.idx; sa.tri_mat = g.tri_mat; sa.ntris_geom = g.ntris;
@@ -482,46 +516,33 @@ int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do
     sa.shadow = ctx->d_shadow; sa.counters = ctx->d_counters;
     sa.bw = ctx->blend;
     dim3 pg((uint32_t)(ctx->W + 15) / 16, (uint32_t)(ctx->H + 15) / 16, 1);
-    if (ctx->counting) hipLaunchKernelGGL(k_shade<true>, pg, dim3(256), 0, ctx->stream, sa);
-    else hipLaunchKernelGGL(k_shade<false>, pg, dim3(256), 0, ctx->stream, sa);
+    if (ctx->counting) hipLaunchKernelGGL(k_shade<true>, pg, dim3(256), 0, ms, sa);
+    else hipLaunchKernelGGL(k_shade<false>, pg, dim3(256), 0, ms, sa);
     // ordered blending of the pixels k_shade flagged: collect, order, shade, blend
     {
         const RasterWS& ws = ctx->geom.ws;
         LayerSink ls{ctx->blend.rp_slot, ctx->d_vis, ctx->blend.bin_flag, ctx->blend.lists, ctx->blend.list_count, ctx->blend.cap};
         hipLaunchKernelGGL((k_raster<kRasterLayers, 1024>), dim3((uint32_t)(ws.bins_x * ws.bins_y), 1, 1), dim3(1024), 0,
-                           ctx->stream, ws, ctx->W, ctx->H, (uint32_t*)nullptr, (float*)nullptr, fc.tile_rank, fc.tile_world, ls);
+                           ms, ws, ctx->W, ctx->H, (uint32_t*)nullptr, (float*)nullptr, fc.tile_rank, fc.tile_world, ls);
         const size_t npx = (size_t)ctx->W * ctx->H;
         const uint32_t slot_groups = (uint32_t)std::min<size_t>((npx + 255) / 256, 2048);
-        hipLaunchKernelGGL(k_resolve, dim3(slot_groups), dim3(256), 0, ctx->stream, sa);
-        if (ctx->counting) hipLaunchKernelGGL(k_replay_slow<true>, dim3(256), dim3(64), 0, ctx->stream, sa);
-        else hipLaunchKernelGGL(k_replay_slow<false>, dim3(256), dim3(64), 0, ctx->stream, sa);
-        hipLaunchKernelGGL(k_shade_frags, dim3((uint32_t)std::min<size_t>((npx + 63) / 64, 16384)), dim3(64), 0, ctx->stream, sa);
-        hipLaunchKernelGGL(k_blend, dim3(slot_groups), dim3(256), 0, ctx->stream, sa);
+        hipLaunchKernelGGL(k_resolve, dim3(slot_groups), dim3(256), 0, ms, sa);
+        if (ctx->counting) hipLaunchKernelGGL(k_replay_slow<true>, dim3(256), dim3(64), 0, ms, sa);
+        else hipLaunchKernelGGL(k_replay_slow<false>, dim3(256), dim3(64), 0, ms, sa);
+        hipLaunchKernelGGL(k_shade_frags, dim3((uint32_t)std::min<size_t>((npx + 63) / 64, 16384)), dim3(64), 0, ms, sa);
+        hipLaunchKernelGGL(k_blend, dim3(slot_groups), dim3(256), 0, ms, sa);
     }
-    if (prof) WR_HIP(hipEventRecord(ev[4], ctx->stream));
+    if (prof) WR_HIP(hipEventRecord(ev[4], ms));
 
+    // main stream: fog colours over the finished geometry colour
+    WR_HIP(hipStreamWaitEvent(ms, ctx->ev_join, 0));
     if (fog_pass) {
-        fa.fc = fc; fa.ws = ctx->fog.ws; fa.pos = fm.pos; fa.idx = fm.idx; fa.ntris = fm.ntris;
-        fa.depth = ctx->d_depth; fa.color = ctx->d_color; fa.shadow = ctx->d_shadow; fa.tables = ctx->d_tables;
-        fa.counters = ctx->d_counters;
-        // the fog workspace has one bin, so its bin_count word is free: it counts march items
-        fa.item_count = ctx->fog.ws.bin_count; fa.item_pixel = ctx->d_fog_pixel; fa.item_ray = ctx->d_fog_ray;
-        dim3 mg((uint32_t)(((size_t)ctx->W * ctx->H + 63) / 64), 1, 1);
-        dim3 fg((uint32_t)(ctx->W + kFogBlock - 1) / kFogBlock, (uint32_t)(ctx->H + kFogBlock - 1) / kFogBlock, 1);
-        if (ctx->counting) {
-            hipLaunchKernelGGL(k_fog_setup<true>, fg, dim3(1024), 0, ctx->stream, fa);
-            if (prof) WR_HIP(hipEventRecord(ev[6], ctx->stream));
-            hipLaunchKernelGGL(k_fog_march<true>, mg, dim3(64), 0, ctx->stream, fa);
-        } else {
-            hipLaunchKernelGGL(k_fog_setup<false>, fg, dim3(1024), 0, ctx->stream, fa);
-            if (prof) WR_HIP(hipEventRecord(ev[6], ctx->stream));
-            hipLaunchKernelGGL(k_fog_march<false>, mg, dim3(64), 0, ctx->stream, fa);
-        }
-    } else if (prof) {
-        WR_HIP(hipEventRecord(ev[6], ctx->stream));
+        hipLaunchKernelGGL(k_fog_blend, dim3(2048), dim3(256), 0, ms, fa);
+        if (ctx->counting) hipLaunchKernelGGL(k_fog_multi<true>, dim3(1024), dim3(64), 0, ms, fa);
+        else hipLaunchKernelGGL(k_fog_multi<false>, dim3(1024), dim3(64), 0, ms, fa);
     }
     if (prof) {
-        WR_HIP(hipEventRecord(ev[5], ctx->stream));
+        WR_HIP(hipEventRecord(ev[7], ms));
         ctx->ev_next = (ctx->ev_next + 1) % WrContext::kEvFrames;
         if (ctx->ev_count < WrContext::kEvFrames) ++ctx->ev_count;
     }
@@ -572,6 +593,8 @@ int wr_create(const WrConfig* config, WrContext** out_ctx) {
         WR_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
         WR_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
         WR_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        WR_HIP(hipEventCreateWithFlags(&ctx->ev_shadow_done, hipEventDisableTiming));
+        WR_HIP(hipEventCreateWithFlags(&ctx->ev_geom_done, hipEventDisableTiming));
         float tables[768];
         build_tables(tables);
         WR_HIP(hipMalloc(&ctx->d_tables, sizeof(tables)));
@@ -605,6 +628,8 @@ void wr_destroy(WrContext* ctx) {
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_shadow_done) (void)hipEventDestroy(ctx->ev_shadow_done);
+    if (ctx->ev_geom_done) (void)hipEventDestroy(ctx->ev_geom_done);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -792,8 +817,9 @@ int wr_get_stats(WrContext* ctx, WrFrameStats* out) {
     int rc = wr_sync(ctx);
     if (rc != WR_OK) return rc;
     if (ctx->ev_count > 0) {
-        // shadow runs on the side stream next to geometry; shade includes any wait for it
-        const int a[6] = {1, 0, 3, 4, 0, 6}, b[6] = {2, 3, 4, 5, 5, 5};  // shadow, geometry, shade, fog, frame, march
+        // shadow runs next to geometry and fog next to shade (side stream); shade includes any
+        // wait for the shadow maps, the frame ends with the fog blend
+        const int a[6] = {1, 0, 3, 8, 0, 6}, b[6] = {2, 3, 4, 5, 7, 5};  // shadow, geometry, shade, fog, frame, march
         double ms[6] = {0, 0, 0, 0, 0, 0};
         for (int f = 0; f < ctx->ev_count; ++f)
             for (int i = 0; i < 6; ++i) {

@@ -1032,6 +1032,9 @@ struct FogArgs {
     uint32_t* item_pixel;  // [W*H] pixel index of each item
     float4* item_ray;      // [W*H] ray origin xyz + max_fog_depth
     NoiseTables tables_noise;  // hash tables of the low octaves (k_fog_tables)
+    float4* item_src;      // [W*H] fog colour of each item (k_fog_march -> k_fog_blend)
+    uint32_t* multi_count; // pixels with several fog fragments, finished by k_fog_multi
+    uint32_t* multi_pixel; // [W*H]
 };
 
 // One fog fragment: interpolate the world position, run the pre-march part of fog.wgsl's
@@ -1075,7 +1078,8 @@ static_assert(sizeof(StagedRec) == 88, "StagedRec layout");
 // per pixel); then every pixel tests the staged records.  A pixel with exactly one fog
 // fragment (always the case for a convex volume) whose march is not empty becomes a work
 // item for k_fog_march, appended with one atomic per workgroup; a pixel with several
-// fragments is finished here, in draw order.
+// fragments is queued for k_fog_multi.  Reads the geometry depth only, not the colour, so the
+// fog pass up to and including the march can run next to the shading kernels.
 constexpr int kFogBlock = 32;
 template <bool COUNT>
 __global__ __launch_bounds__(1024) void k_fog_setup(FogArgs a) {
@@ -1157,8 +1161,32 @@ __global__ __launch_bounds__(1024) void k_fog_setup(FogArgs a) {
         origin = v3(ip(B, w[0].x, w[1].x, w[2].x), ip(B, w[0].y, w[1].y, w[2].y), ip(B, w[0].z, w[1].z, w[2].z));
         max_depth = fog_max_depth(a.fc, a.depth, hit_z, px, py);
     }
-    if (nfrag >= 2) {
-        // several fog fragments on one pixel: blend them here, one after the other
+    if (COUNT && nfrag == 1) atomicAdd(&a.counters[0], 1ull);
+    const bool item = nfrag == 1 && max_depth > 0.0f;
+    if (__syncthreads_or(nfrag >= 2 ? 1 : 0)) {
+        // several fog fragments on one pixel (a fog volume that is not convex): left to k_fog_multi
+        const uint32_t m = group_append(a.multi_count, nfrag >= 2 ? 1u : 0u, &s_cnt, &s_base);
+        if (nfrag >= 2) a.multi_pixel[m] = (uint32_t)pi;
+    }
+    if (!__syncthreads_or(item ? 1 : 0)) return;
+    const uint32_t k = group_append(a.item_count, item ? 1u : 0u, &s_cnt, &s_base);
+    if (item) {
+        a.item_pixel[k] = (uint32_t)pi;
+        a.item_ray[k] = make_float4(origin.x, origin.y, origin.z, max_depth);
+    }
+}
+
+// Fog pass for the pixels k_fog_setup found covered by several fog fragments: every fragment
+// that passes the depth test is marched and blended over the pixel in draw order.  Runs after
+// the geometry colour is final.
+template <bool COUNT>
+__global__ __launch_bounds__(64) void k_fog_multi(FogArgs a) {
+    const uint32_t n = *a.multi_count;
+    if (blockIdx.x * 64u >= n) return;
+    for (uint32_t k = blockIdx.x * 64u + threadIdx.x; k < n; k += gridDim.x * 64u) {
+        const uint32_t pi = a.multi_pixel[k];
+        const int px = (int)(pi % (uint32_t)a.fc.W), py = (int)(pi / (uint32_t)a.fc.W);
+        const float zbuf = a.depth[pi];
         ColorTables ct{a.tables};
         ShadowMap sm{a.shadow, a.fc.S};
         uint32_t col = a.color[pi];
@@ -1187,14 +1215,6 @@ __global__ __launch_bounds__(1024) void k_fog_setup(FogArgs a) {
         }
         a.color[pi] = col;
     }
-    if (COUNT && nfrag == 1) atomicAdd(&a.counters[0], 1ull);
-    const bool item = nfrag == 1 && max_depth > 0.0f;
-    if (!__syncthreads_or(item ? 1 : 0)) return;
-    const uint32_t k = group_append(a.item_count, item ? 1u : 0u, &s_cnt, &s_base);
-    if (item) {
-        a.item_pixel[k] = (uint32_t)pi;
-        a.item_ray[k] = make_float4(origin.x, origin.y, origin.z, max_depth);
-    }
 }
 
 // Fills the hash table of one noise level: entry (i,j,k) = hash of lattice point lo + (i,j,k).
@@ -1208,21 +1228,34 @@ __global__ __launch_bounds__(256) void k_fog_tables(NoiseTables nt) {
     const_cast<float*>(t.data)[i] = lattice_hash((float)(t.lox + ix), (float)(t.loy + iy), (float)(t.loz + iz));
 }
 
-// Fog pass, part 2: one thread per work item runs both marches of fog.wgsl and blends the
-// fog colour over the pixel (SrcAlpha / OneMinusSrcAlpha, state.rs:501).  One wavefront per
-// workgroup, all lanes busy, so the long-running marches spread evenly over the chip.
+// Fog pass, part 2: one thread per work item runs both marches of fog.wgsl and stores the fog
+// colour of the item.  One wavefront per workgroup, all lanes busy, so the long-running
+// marches spread evenly over the chip.
 template <bool COUNT>
 __global__ __launch_bounds__(64) void k_fog_march(FogArgs a) {
     const uint32_t k = blockIdx.x * 64u + threadIdx.x;
     if (k >= *a.item_count) return;
-    const uint32_t pi = a.item_pixel[k];
     const float4 ray = a.item_ray[k];
-    ColorTables ct{a.tables};
     ShadowMap sm{a.shadow, a.fc.S};
     uint32_t evals = 0;
     V4 src = fog_march_shade(a.fc, sm, &a.tables_noise, v3(ray.x, ray.y, ray.z), ray.w, evals);
     if (COUNT) atomicAdd(&a.counters[1], (unsigned long long)evals);
-    a.color[pi] = blend_pack(ct, a.color[pi], src, true);
+    a.item_src[k] = make_float4(src.x, src.y, src.z, src.w);
+}
+
+// Fog pass, part 3: blends the marched fog colours over the finished geometry colour
+// (SrcAlpha / OneMinusSrcAlpha, state.rs:501).
+__global__ __launch_bounds__(256) void k_fog_blend(FogArgs a) {
+    __shared__ float s_tab[768];
+    const uint32_t n = *a.item_count;
+    if (blockIdx.x * 256u >= n) return;
+    stage_color_tables(s_tab, a.tables);
+    ColorTables ct{s_tab};
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n; k += gridDim.x * 256u) {
+        const uint32_t pi = a.item_pixel[k];
+        const float4 c = a.item_src[k];
+        a.color[pi] = blend_pack(ct, a.color[pi], V4{c.x, c.y, c.z, c.w}, true);
+    }
 }
 
 // ------------------------------------------------------------------ bin pack / scatter
