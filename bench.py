@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--poses", type=int, default=512)
+    ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2],
+                    help="sets of frame buffers the library alternates between (WrConfig.frames_in_flight)")
     args = ap.parse_args()
 
     import torch
@@ -133,7 +135,9 @@ def main():
     cam = abi.camera_uniform(rc["position"], rc["pitch"], rc["yaw"], rc["fovy"], W, H)
 
     tile_world = world if args.workload == "tiles4k" else 1
-    r = abi.Renderer(W, H, S, device=local_rank, tile_rank=rank if tile_world > 1 else 0, tile_world=tile_world)
+    in_flight = 1 if args.workload == "tiles4k" else args.frames_in_flight
+    r = abi.Renderer(W, H, S, device=local_rank, tile_rank=rank if tile_world > 1 else 0, tile_world=tile_world,
+                     frames_in_flight=in_flight)
     r.upload_scene(sc)
 
     def barrier():
@@ -263,6 +267,7 @@ def main():
                 "materials": len(sc.geometry.materials),
                 "texture_size": args.tex_size if "stand-in" in scene_name else None,
                 "parallelism": f"frame-parallel x{world}" if args.workload != "tiles4k" else f"screen-bin sharded x{world}",
+                "frames_in_flight": in_flight,
             },
             "stage_ms": stage_ms,
             "fog_fragments": fog_frags,

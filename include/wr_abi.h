@@ -117,8 +117,18 @@ typedef struct WrConfig {
      * renders the whole frame. */
     uint32_t tile_rank;
     uint32_t tile_world;
-    /* hipStream_t to run on, or NULL for a library-owned stream. */
+    /* hipStream_t the frames are ordered against, or NULL for a library-owned stream.  A frame
+     * starts after the work queued on this stream before the wr_render_* call; its kernels run
+     * on library-owned streams. */
     void* stream;
+    /* Frames in flight (the reference's surface keeps more than one frame in flight as well,
+     * state.rs:631,806).  0 or 1: a frame's work is complete, as seen from `stream`, before
+     * anything queued on `stream` afterwards.  2: consecutive frames use alternate sets of frame
+     * buffers and overlap on the device; a frame's results are complete after wr_sync (every
+     * wr_read_* and wr_get_stats syncs), and read-back / wr_color_device_ptr refer to the most
+     * recently submitted frame. */
+    uint32_t frames_in_flight;
+    uint32_t reserved;
 } WrConfig;
 
 typedef struct WrContext WrContext;

@@ -251,6 +251,46 @@ def test_fog_volume_with_overlapping_parts(tiny_scene):
     assert g["counters"]["fog_fragments"] > g1["counters"]["fog_fragments"]  # the slab added fragments
 
 
+def test_two_frames_in_flight_match_one(small_scene):
+    """Consecutive frames on alternate sets of frame buffers, overlapping on the device, give
+    the same pixels as one frame at a time; the light moves between frames, so every frame
+    needs its own shadow maps."""
+    import torch
+    w, h, s = 400, 225, 256
+    poses = [scene.flythrough_pose(k, 64) for k in (0, 9, 21, 40, 63)]
+    cams = [default_inputs(w, h, pose=p)[0] for p in poses]
+    lights = [abi.light_at_time(1.0 + 0.7 * k) for k in range(len(cams))]
+    globs = [abi.global_uniforms(1.0 + 0.7 * k, 1) for k in range(len(cams))]
+    one = abi.Renderer(w, h, s)
+    one.upload_scene(small_scene)
+    ref = []
+    for c, l, g in zip(cams, lights, globs):
+        one.render_frame(c, l, g, abi.PASS_ALL)
+        ref.append((one.read_color(), one.read_depth(), one.read_shadow_map()))
+    one.close()
+    two = abi.Renderer(w, h, s, frames_in_flight=2)
+    two.upload_scene(small_scene)
+    for n in (2, 3, 5):  # submit n frames back to back, then look at the last one
+        for c, l, g in list(zip(cams, lights, globs))[:n]:
+            two.render_frame(c, l, g, abi.PASS_ALL)
+        assert np.array_equal(two.read_color(), ref[n - 1][0])
+        assert np.array_equal(two.read_depth(), ref[n - 1][1])
+        assert np.array_equal(two.read_shadow_map(), ref[n - 1][2])
+    # every frame of a batch, delivered to device memory
+    frames = torch.zeros((len(cams), h, w, 4), dtype=torch.uint8, device="cuda")
+    two.render_batch(cams, lights[0], globs[0], abi.PASS_ALL, shadows_every_frame=True, device_frames=frames.data_ptr())
+    two.sync()
+    torch.cuda.synchronize()
+    got = frames.cpu().numpy()
+    chk = abi.Renderer(w, h, s)
+    chk.upload_scene(small_scene)
+    for k, c in enumerate(cams):
+        chk.render_frame(c, lights[0], globs[0], abi.PASS_ALL)
+        assert np.array_equal(chk.read_color(), got[k]), k
+    chk.close()
+    two.close()
+
+
 def test_draw_orders_give_different_images():
     w, h, s = 160, 120, 64
     cam = abi.camera_uniform((0.0, 0.0, 500.0), 0.0, -90.0, 55.0, w, h)

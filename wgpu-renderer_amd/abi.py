@@ -72,6 +72,8 @@ class Config(C.Structure):
         ("tile_rank", C.c_uint32),
         ("tile_world", C.c_uint32),
         ("stream", C.c_void_p),
+        ("frames_in_flight", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 
@@ -204,9 +206,9 @@ class Renderer:
     keeps its wgpu Device/Queue/pipelines (state.rs:30-66)."""
 
     def __init__(self, width: int, height: int, shadow_map_size: int = 2048, device: int = 0,
-                 tile_rank: int = 0, tile_world: int = 1, stream: Optional[int] = None):
+                 tile_rank: int = 0, tile_world: int = 1, stream: Optional[int] = None, frames_in_flight: int = 1):
         self.lib = load_library()
-        cfg = Config(width, height, shadow_map_size, 0, device, tile_rank, tile_world, stream)
+        cfg = Config(width, height, shadow_map_size, 0, device, tile_rank, tile_world, stream, frames_in_flight, 0)
         h = _P()
         rc = self.lib.wr_create(C.byref(cfg), C.byref(h))
         if rc != WR_OK:

@@ -63,15 +63,37 @@ struct WsAlloc {
 
 }  // namespace
 
+// Everything one frame in flight writes: with two of these, consecutive frames use alternate
+// sets (and their own pair of streams), so the early, latency-bound stages of one frame run
+// under the fog march of the frame before it.
+struct FrameRes {
+    // ms: geometry pass, shading, fog blend.  ss: shadow pass, then (once the geometry depth
+    // exists) the fog pass up to and including the march, next to the shading kernels.
+    hipStream_t ms = nullptr, side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_start = nullptr, ev_join = nullptr, ev_shadow_done = nullptr, ev_geom_done = nullptr, ev_done = nullptr;
+    bool submitted = false;  // ev_done has been recorded
+
+    VertexOut vout{};
+    float4* d_shadow_clip = nullptr;
+    WsAlloc geom, shadow, fog;
+    uint32_t* d_vis = nullptr;
+    float* d_depth = nullptr;
+    uint32_t* d_color = nullptr;
+    float* d_shadow = nullptr;
+    BlendWS blend{};                 // ordered-blend work space, sized with the colour target
+    size_t blend_clear_bytes = 0;    // counts + bin flags, cleared every frame
+    float* d_noise_pool = nullptr;   // hash tables of the low noise octaves, rebuilt every frame
+    uint32_t* d_fog_pixel = nullptr; // [W*H] fog march work items: pixel index
+    float4* d_fog_ray = nullptr;     // [W*H] ray origin + max_fog_depth
+    float4* d_fog_src = nullptr;     // [W*H] marched fog colour of each item
+    uint32_t* d_fog_multi = nullptr; // [W*H] pixels with several fog fragments
+};
+
 struct WrContext {
     WrConfig cfg{};
     int W = 0, H = 0, S = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;  // the caller's stream (or a library-owned one): submission order, read-back
     bool own_stream = false;
-    // The shadow pass depends only on the frame's uniforms, so it runs on a side stream next to
-    // the geometry pass; the shading kernels wait for it.
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_shadow_done = nullptr, ev_geom_done = nullptr;
     std::string err;
 
     ModelHost host[3];
@@ -83,27 +105,17 @@ struct WrContext {
     TexDesc* d_tex = nullptr;
     uint32_t* d_texels = nullptr;
     float* d_tables = nullptr;
-
-    VertexOut vout{};
-    float4* d_shadow_clip = nullptr;
-    WsAlloc geom, shadow, fog;
-    uint32_t* d_vis = nullptr;
-    float* d_depth = nullptr;
-    uint32_t* d_color = nullptr;
-    float* d_shadow = nullptr;
-    unsigned long long* d_counters = nullptr;
-    BlendWS blend{};                 // ordered-blend work space, sized with the colour target
-    size_t blend_clear_bytes = 0;    // counts + bin flags, cleared every frame
-    float* d_noise_pool = nullptr;   // hash tables of the low noise octaves, rebuilt every frame
     float fog_aabb[6] = {0, 0, 0, 0, 0, 0};  // fog model bounds in model space (min xyz, max xyz)
-    uint32_t* d_fog_pixel = nullptr; // [W*H] fog march work items: pixel index
-    float4* d_fog_ray = nullptr;     // [W*H] ray origin + max_fog_depth
-    float4* d_fog_src = nullptr;     // [W*H] marched fog colour of each item
-    uint32_t* d_fog_multi = nullptr; // [W*H] pixels with several fog fragments
+
+    static constexpr int kMaxFrames = 2;
+    FrameRes fr[kMaxFrames];
+    int nfr = 1;   // frames in flight (WrConfig.frames_in_flight)
+    int cur = 0;   // the set the most recent frame was submitted to
+    unsigned long long* d_counters = nullptr;
     uint32_t* d_err = nullptr;  // [0] error bits, [1] geometry bin items, [2] shadow bin items, [3] fog (unused)
 
     bool profiling = false, counting = false;
-    // Profiling keeps one set of five stage-boundary events per frame in a ring; wr_get_stats
+    // Profiling keeps one set of stage-boundary events per frame in a ring; wr_get_stats
     // averages the stage times over the frames recorded since profiling was switched on.
     static constexpr int kEvFrames = 128;
     static constexpr int kEvPerFrame = 9;  // see frame_stages
@@ -164,11 +176,13 @@ int alloc_ws(WrContext* ctx, WsAlloc& w, uint32_t slots, uint32_t ovf_cap, uint3
 }
 
 void free_targets(WrContext* c) {
-    dfree(c->d_vis); dfree(c->d_depth); dfree(c->d_color); dfree(c->d_fog_pixel); dfree(c->d_fog_ray); dfree(c->d_fog_src); dfree(c->d_fog_multi);
-    BlendWS& b = c->blend;
-    dfree(b.rp_slot); dfree(b.slot_pixel); dfree(b.counts); dfree(b.lists); dfree(b.list_count);
-    dfree(b.slow_slots); dfree(b.slot_frags); dfree(b.frag_item); dfree(b.frag_src);
-    b = BlendWS();
+    for (FrameRes& f : c->fr) {
+        dfree(f.d_vis); dfree(f.d_depth); dfree(f.d_color); dfree(f.d_fog_pixel); dfree(f.d_fog_ray); dfree(f.d_fog_src); dfree(f.d_fog_multi);
+        BlendWS& b = f.blend;
+        dfree(b.rp_slot); dfree(b.slot_pixel); dfree(b.counts); dfree(b.lists); dfree(b.list_count);
+        dfree(b.slow_slots); dfree(b.slot_frags); dfree(b.frag_item); dfree(b.frag_src);
+        b = BlendWS();
+    }
 }
 void free_scene(WrContext* c) {
     for (int m = 0; m < 3; ++m) {
@@ -177,47 +191,65 @@ void free_scene(WrContext* c) {
         d = ModelDev();
     }
     dfree(c->d_mats); dfree(c->d_tex); dfree(c->d_texels);
-    dfree(c->vout.clip); dfree(c->vout.v0); dfree(c->vout.v1); dfree(c->vout.v2); dfree(c->vout.v3);
-    dfree(c->d_shadow_clip);
-    free_ws(c->geom); free_ws(c->shadow); free_ws(c->fog);
+    for (FrameRes& f : c->fr) {
+        dfree(f.vout.clip); dfree(f.vout.v0); dfree(f.vout.v1); dfree(f.vout.v2); dfree(f.vout.v3);
+        dfree(f.d_shadow_clip);
+        free_ws(f.geom); free_ws(f.shadow); free_ws(f.fog);
+    }
 }
 
 int alloc_targets(WrContext* ctx) {
     free_targets(ctx);
     size_t n = (size_t)ctx->W * ctx->H;
-    WR_HIP(hipMalloc(&ctx->d_vis, n * 4));
-    WR_HIP(hipMalloc(&ctx->d_depth, n * 4));
-    WR_HIP(hipMalloc(&ctx->d_color, n * 4));
-    // Ordered blending: every pixel can be flagged, and every flagged pixel keeps up to
-    // kReplayK covering fragments (128 bytes per pixel of the target; only flagged pixels'
-    // lists are ever touched).
-    BlendWS& b = ctx->blend;
-    const size_t nbins = (size_t)((ctx->W + kBin - 1) / kBin) * (size_t)((ctx->H + kBin - 1) / kBin);
-    b.cap = (uint32_t)n; b.frag_cap = (uint32_t)n;
-    ctx->blend_clear_bytes = sizeof(uint32_t) * (4 + nbins);
-    WR_HIP(hipMalloc(&b.rp_slot, n * 4));
-    WR_HIP(hipMalloc(&b.slot_pixel, n * 4));
-    WR_HIP(hipMalloc(&b.counts, ctx->blend_clear_bytes));
-    b.bin_flag = b.counts + 4;
-    WR_HIP(hipMalloc(&b.lists, n * kReplayK * sizeof(uint2)));
-    WR_HIP(hipMalloc(&b.list_count, n * 4));
-    WR_HIP(hipMalloc(&b.slow_slots, n * 4));
-    WR_HIP(hipMalloc(&b.slot_frags, n * sizeof(uint2)));
-    WR_HIP(hipMalloc(&b.frag_item, n * sizeof(uint2)));
-    WR_HIP(hipMalloc(&b.frag_src, n * sizeof(float4)));
-    WR_HIP(hipMemset(b.rp_slot, 0, n * 4));
-    WR_HIP(hipMalloc(&ctx->d_fog_pixel, n * 4));
-    WR_HIP(hipMalloc(&ctx->d_fog_ray, n * sizeof(float4)));
-    WR_HIP(hipMalloc(&ctx->d_fog_src, n * sizeof(float4)));
-    WR_HIP(hipMalloc(&ctx->d_fog_multi, n * 4));
-    WR_HIP(hipMemset(ctx->d_color, 0, n * 4));
+    for (int k = 0; k < ctx->nfr; ++k) {
+        FrameRes* f = &ctx->fr[k];
+        WR_HIP(hipMalloc(&f->d_vis, n * 4));
+        WR_HIP(hipMalloc(&f->d_depth, n * 4));
+        WR_HIP(hipMalloc(&f->d_color, n * 4));
+        // Ordered blending: every pixel can be flagged, and every flagged pixel keeps up to
+        // kReplayK covering fragments (128 bytes per pixel of the target; only flagged pixels'
+        // lists are ever touched).
+        BlendWS& b = f->blend;
+        const size_t nbins = (size_t)((ctx->W + kBin - 1) / kBin) * (size_t)((ctx->H + kBin - 1) / kBin);
+        b.cap = (uint32_t)n; b.frag_cap = (uint32_t)n;
+        f->blend_clear_bytes = sizeof(uint32_t) * (4 + nbins);
+        WR_HIP(hipMalloc(&b.rp_slot, n * 4));
+        WR_HIP(hipMalloc(&b.slot_pixel, n * 4));
+        WR_HIP(hipMalloc(&b.counts, f->blend_clear_bytes));
+        b.bin_flag = b.counts + 4;
+        WR_HIP(hipMalloc(&b.lists, n * kReplayK * sizeof(uint2)));
+        WR_HIP(hipMalloc(&b.list_count, n * 4));
+        WR_HIP(hipMalloc(&b.slow_slots, n * 4));
+        WR_HIP(hipMalloc(&b.slot_frags, n * sizeof(uint2)));
+        WR_HIP(hipMalloc(&b.frag_item, n * sizeof(uint2)));
+        WR_HIP(hipMalloc(&b.frag_src, n * sizeof(float4)));
+        WR_HIP(hipMemset(b.rp_slot, 0, n * 4));
+        WR_HIP(hipMalloc(&f->d_fog_pixel, n * 4));
+        WR_HIP(hipMalloc(&f->d_fog_ray, n * sizeof(float4)));
+        WR_HIP(hipMalloc(&f->d_fog_src, n * sizeof(float4)));
+        WR_HIP(hipMalloc(&f->d_fog_multi, n * 4));
+        WR_HIP(hipMemset(f->d_color, 0, n * 4));
+    }
+    return WR_OK;
+}
+
+// Waits for every frame in flight and for the caller's stream.
+int sync_all(WrContext* ctx) {
+    for (int k = 0; k < ctx->nfr; ++k) {
+        if (ctx->fr[k].ms) WR_HIP(hipStreamSynchronize(ctx->fr[k].ms));
+        if (ctx->fr[k].side) WR_HIP(hipStreamSynchronize(ctx->fr[k].side));
+    }
+    WR_HIP(hipStreamSynchronize(ctx->stream));
     return WR_OK;
 }
 
 // (Re)builds every device buffer that depends on the uploaded scene or the target size.
 int build_scene(WrContext* ctx) {
     WR_HIP(hipSetDevice(ctx->cfg.device));
-    WR_HIP(hipStreamSynchronize(ctx->stream));
+    {
+        int rcs = sync_all(ctx);
+        if (rcs != WR_OK) return rcs;
+    }
     free_scene(ctx);
     for (int m = 0; m < 3; ++m) {
         ModelHost& h = ctx->host[m];
@@ -295,30 +327,33 @@ int build_scene(WrContext* ctx) {
     const uint32_t ntl = ctx->dev[WR_MODEL_LIGHT_MARKER].ntris, ntf = ctx->dev[WR_MODEL_FOG_VOLUME].ntris;
     if ((uint64_t)ntg + ntl >= (1u << 29)) return fail(ctx, WR_ERR_UNSUPPORTED, "more than 2^29 triangles");
     size_t nvs = std::max<uint32_t>(nvg, 1);
-    WR_HIP(hipMalloc(&ctx->vout.clip, sizeof(float4) * nvs));
-    WR_HIP(hipMalloc(&ctx->vout.v0, sizeof(float4) * nvs));
-    WR_HIP(hipMalloc(&ctx->vout.v1, sizeof(float4) * nvs));
-    WR_HIP(hipMalloc(&ctx->vout.v2, sizeof(float4) * nvs));
-    WR_HIP(hipMalloc(&ctx->vout.v3, sizeof(float4) * nvs));
-    WR_HIP(hipMalloc(&ctx->d_shadow_clip, sizeof(float4) * nvs * 6));
-    int rc;
-    {
-        uint32_t slots = ntg + ntl;
-        uint32_t ovf = slots / 2 + 8192;
-        int bx = (ctx->W + kBin - 1) / kBin, by = (ctx->H + kBin - 1) / kBin;
-        uint32_t items = 8u * (slots + ovf) + 64u * (uint32_t)(bx * by) + (1u << 20);
-        if ((rc = alloc_ws(ctx, ctx->geom, std::max(slots, 1u), ovf, items, bx, by, 1, ctx->d_err, ctx->d_err + 1)) != WR_OK) return rc;
-    }
-    {
-        uint32_t slots = std::max(ntg, 1u);
-        uint32_t ovf = slots / 4 + 8192;
-        int bs = (ctx->S + kBin - 1) / kBin;
-        uint32_t items = 6u * (4u * slots + 64u * (uint32_t)(bs * bs) + (1u << 18));
-        if ((rc = alloc_ws(ctx, ctx->shadow, slots, ovf, items, bs, bs, 6, ctx->d_err, ctx->d_err + 2)) != WR_OK) return rc;
-    }
-    {
-        uint32_t slots = std::max(ntf, 1u);
-        if ((rc = alloc_ws(ctx, ctx->fog, slots, slots * kMaxFan + 8, 8, 1, 1, 1, ctx->d_err, ctx->d_err + 3)) != WR_OK) return rc;
+    for (int k = 0; k < ctx->nfr; ++k) {
+        FrameRes* f = &ctx->fr[k];
+        WR_HIP(hipMalloc(&f->vout.clip, sizeof(float4) * nvs));
+        WR_HIP(hipMalloc(&f->vout.v0, sizeof(float4) * nvs));
+        WR_HIP(hipMalloc(&f->vout.v1, sizeof(float4) * nvs));
+        WR_HIP(hipMalloc(&f->vout.v2, sizeof(float4) * nvs));
+        WR_HIP(hipMalloc(&f->vout.v3, sizeof(float4) * nvs));
+        WR_HIP(hipMalloc(&f->d_shadow_clip, sizeof(float4) * nvs * 6));
+        int rc;
+        {
+            uint32_t slots = ntg + ntl;
+            uint32_t ovf = slots / 2 + 8192;
+            int bx = (ctx->W + kBin - 1) / kBin, by = (ctx->H + kBin - 1) / kBin;
+            uint32_t items = 8u * (slots + ovf) + 64u * (uint32_t)(bx * by) + (1u << 20);
+            if ((rc = alloc_ws(ctx, f->geom, std::max(slots, 1u), ovf, items, bx, by, 1, ctx->d_err, ctx->d_err + 1)) != WR_OK) return rc;
+        }
+        {
+            uint32_t slots = std::max(ntg, 1u);
+            uint32_t ovf = slots / 4 + 8192;
+            int bs = (ctx->S + kBin - 1) / kBin;
+            uint32_t items = 6u * (4u * slots + 64u * (uint32_t)(bs * bs) + (1u << 18));
+            if ((rc = alloc_ws(ctx, f->shadow, slots, ovf, items, bs, bs, 6, ctx->d_err, ctx->d_err + 2)) != WR_OK) return rc;
+        }
+        {
+            uint32_t slots = std::max(ntf, 1u);
+            if ((rc = alloc_ws(ctx, f->fog, slots, slots * kMaxFan + 8, 8, 1, 1, 1, ctx->d_err, ctx->d_err + 3)) != WR_OK) return rc;
+        }
     }
     ctx->scene_dirty = false;
     return WR_OK;
@@ -356,7 +391,7 @@ FrameConsts make_consts(const WrContext* ctx, const WrCameraUniform* cam, const 
 
 dim3 grid1(uint32_t n, uint32_t layers = 1) { return dim3((n + 255u) / 256u, layers, 1); }
 
-int bin_and_raster(WrContext* ctx, hipStream_t st, WsAlloc& w, bool shadow, int tr, int tw) {
+int bin_and_raster(WrContext* ctx, FrameRes* f, hipStream_t st, WsAlloc& w, bool shadow, int tr, int tw) {
     RasterWS& ws = w.ws;
     uint32_t nrec = ws.slots + ws.ovf_cap;
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, ws);
@@ -364,33 +399,33 @@ int bin_and_raster(WrContext* ctx, hipStream_t st, WsAlloc& w, bool shadow, int 
     dim3 g((uint32_t)(ws.bins_x * ws.bins_y), (uint32_t)ws.layers, 1);
     if (shadow)
         hipLaunchKernelGGL((k_raster<kRasterShadow, 256>), g, dim3(256), 0, st, ws, ctx->S, ctx->S, (uint32_t*)nullptr,
-                           ctx->d_shadow, 0, 1, LayerSink{});
+                           f->d_shadow, 0, 1, LayerSink{});
     else
-        hipLaunchKernelGGL((k_raster<kRasterColor, 1024>), g, dim3(1024), 0, st, ws, ctx->W, ctx->H, ctx->d_vis,
-                           ctx->d_depth, tr, tw, LayerSink{});
+        hipLaunchKernelGGL((k_raster<kRasterColor, 1024>), g, dim3(1024), 0, st, ws, ctx->W, ctx->H, f->d_vis,
+                           f->d_depth, tr, tw, LayerSink{});
     return WR_OK;
 }
 
-int shadow_stage(WrContext* ctx, hipStream_t st, const FrameConsts& fc) {
+int shadow_stage(WrContext* ctx, FrameRes* f, hipStream_t st, const FrameConsts& fc) {
     const ModelDev& g = ctx->dev[WR_MODEL_GEOMETRY];
     {
         ClearList cl{};
-        cl.ptr[0] = ctx->shadow.counters; cl.words[0] = (uint32_t)(ctx->shadow.counters_bytes / 4);
+        cl.ptr[0] = f->shadow.counters; cl.words[0] = (uint32_t)(f->shadow.counters_bytes / 4);
         hipLaunchKernelGGL(k_clear_words, dim3(32), dim3(256), 0, st, cl);
     }
-    hipLaunchKernelGGL(k_vs_shadow, grid1(g.nv, 6), dim3(256), 0, st, g.pos, g.nv, ctx->d_shadow_clip, fc);
-    hipLaunchKernelGGL(k_setup<true>, grid1(g.ntris, 6), dim3(256), 0, st, ctx->d_shadow_clip, g.nv, g.idx, g.ntris,
-                       ctx->shadow.ws, ctx->S, ctx->S, 0, 1);
-    hipLaunchKernelGGL(k_setup_clip<true>, dim3(128, 6, 1), dim3(64), 0, st, ctx->d_shadow_clip, g.nv, g.idx, ctx->shadow.ws,
+    hipLaunchKernelGGL(k_vs_shadow, grid1(g.nv, 6), dim3(256), 0, st, g.pos, g.nv, f->d_shadow_clip, fc);
+    hipLaunchKernelGGL(k_setup<true>, grid1(g.ntris, 6), dim3(256), 0, st, f->d_shadow_clip, g.nv, g.idx, g.ntris,
+                       f->shadow.ws, ctx->S, ctx->S, 0, 1);
+    hipLaunchKernelGGL(k_setup_clip<true>, dim3(128, 6, 1), dim3(64), 0, st, f->d_shadow_clip, g.nv, g.idx, f->shadow.ws,
                        ctx->S, ctx->S, 0, 1);
-    return bin_and_raster(ctx, st, ctx->shadow, true, 0, 1);
+    return bin_and_raster(ctx, f, st, f->shadow, true, 0, 1);
 }
 
 // Chooses which noise levels get a hash table this frame.  Every march sample lies within
 // the fog volume's world box grown by the longest march (30*5 + 10*10 units); a level is
 // tabled when its lattice over that box fits the per-level and pool budgets.  Samples that
 // still fall outside (they cannot, short of non-finite inputs) are evaluated directly.
-NoiseTables plan_noise_tables(const WrContext* ctx, const FrameConsts& fc, uint32_t* max_entries) {
+NoiseTables plan_noise_tables(const WrContext* ctx, const FrameRes* f, const FrameConsts& fc, uint32_t* max_entries) {
     NoiseTables nt;
     memset(&nt, 0, sizeof(nt));
     *max_entries = 0;
@@ -418,7 +453,7 @@ NoiseTables plan_noise_tables(const WrContext* ctx, const FrameConsts& fc, uint3
             double entries = (double)n[0] * n[1] * n[2];
             if (entries > (double)kNoiseLevelEntries || used + (size_t)entries > kNoisePoolEntries) continue;
             NoiseTable& t = nt.level[k * 8 + o];
-            t.data = ctx->d_noise_pool + used;
+            t.data = f->d_noise_pool + used;
             t.lox = (int)l[0]; t.loy = (int)l[1]; t.loz = (int)l[2];
             t.nx = (int)n[0]; t.ny = (int)n[1]; t.nz = (int)n[2];
             used += (size_t)entries;
@@ -433,66 +468,69 @@ NoiseTables plan_noise_tables(const WrContext* ctx, const FrameConsts& fc, uint3
 // Profiling events of a frame: [0] frame start, [3] geometry end, [4] shade end, [7] frame end
 // on the main stream; [1] shadow start, [2] shadow end, [8] fog start, [6] march start,
 // [5] march end on the side stream.
-int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do_shadow) {
+int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t passes, bool do_shadow) {
     const ModelDev& g = ctx->dev[WR_MODEL_GEOMETRY];
     const ModelDev& lm = ctx->dev[WR_MODEL_LIGHT_MARKER];
     const ModelDev& fm = ctx->dev[WR_MODEL_FOG_VOLUME];
     const bool prof = ctx->profiling;
     hipEvent_t* ev = ctx->ev[ctx->ev_next];
-    hipStream_t ms = ctx->stream, ss = ctx->side;
+    hipStream_t ms = f->ms, ss = f->side;
     int rc;
+    // order the frame after what the caller has queued on its stream so far
+    WR_HIP(hipEventRecord(f->ev_fork, ctx->stream));
+    WR_HIP(hipStreamWaitEvent(ms, f->ev_fork, 0));
     if (prof) WR_HIP(hipEventRecord(ev[0], ms));
     const bool fog_pass = (passes & WR_PASS_FOG) && fm.ntris;
 
     // side stream: shadow maps
-    WR_HIP(hipEventRecord(ctx->ev_fork, ms));
-    WR_HIP(hipStreamWaitEvent(ss, ctx->ev_fork, 0));
+    WR_HIP(hipEventRecord(f->ev_start, ms));  // after this set's previous frame and the caller's earlier work
+    WR_HIP(hipStreamWaitEvent(ss, f->ev_start, 0));
     if (prof) WR_HIP(hipEventRecord(ev[1], ss));
     if (do_shadow && (passes & WR_PASS_SHADOWS))
-        if ((rc = shadow_stage(ctx, ss, fc)) != WR_OK) return rc;
+        if ((rc = shadow_stage(ctx, f, ss, fc)) != WR_OK) return rc;
     if (prof) WR_HIP(hipEventRecord(ev[2], ss));
-    WR_HIP(hipEventRecord(ctx->ev_shadow_done, ss));
+    WR_HIP(hipEventRecord(f->ev_shadow_done, ss));
 
     // main stream: geometry + light marker -> visibility / depth
     {
         ClearList cl{};
-        cl.ptr[0] = ctx->geom.counters; cl.words[0] = (uint32_t)(ctx->geom.counters_bytes / 4);
-        cl.ptr[1] = ctx->blend.counts; cl.words[1] = (uint32_t)(ctx->blend_clear_bytes / 4);
-        if (fog_pass) { cl.ptr[2] = ctx->fog.counters; cl.words[2] = (uint32_t)(ctx->fog.counters_bytes / 4); }
+        cl.ptr[0] = f->geom.counters; cl.words[0] = (uint32_t)(f->geom.counters_bytes / 4);
+        cl.ptr[1] = f->blend.counts; cl.words[1] = (uint32_t)(f->blend_clear_bytes / 4);
+        if (fog_pass) { cl.ptr[2] = f->fog.counters; cl.words[2] = (uint32_t)(f->fog.counters_bytes / 4); }
         hipLaunchKernelGGL(k_clear_words, dim3(8), dim3(256), 0, ms, cl);
     }
     VertexIn vin{g.pos, g.uv, g.nrm, g.tan, g.bit, g.nv};
-    hipLaunchKernelGGL(k_vs_geometry, grid1(g.nv), dim3(256), 0, ms, vin, ctx->vout, fc);
-    hipLaunchKernelGGL(k_setup<false>, grid1(g.ntris, 1), dim3(256), 0, ms, ctx->vout.clip, g.nv, g.idx, g.ntris,
-                       ctx->geom.ws, ctx->W, ctx->H, fc.tile_rank, fc.tile_world);
-    hipLaunchKernelGGL(k_setup_clip<false>, dim3(256, 1, 1), dim3(64), 0, ms, ctx->vout.clip, g.nv, g.idx, ctx->geom.ws,
+    hipLaunchKernelGGL(k_vs_geometry, grid1(g.nv), dim3(256), 0, ms, vin, f->vout, fc);
+    hipLaunchKernelGGL(k_setup<false>, grid1(g.ntris, 1), dim3(256), 0, ms, f->vout.clip, g.nv, g.idx, g.ntris,
+                       f->geom.ws, ctx->W, ctx->H, fc.tile_rank, fc.tile_world);
+    hipLaunchKernelGGL(k_setup_clip<false>, dim3(256, 1, 1), dim3(64), 0, ms, f->vout.clip, g.nv, g.idx, f->geom.ws,
                        ctx->W, ctx->H, fc.tile_rank, fc.tile_world);
     if (lm.ntris)
         hipLaunchKernelGGL(k_setup_small, grid1(lm.ntris), dim3(256), 0, ms, lm.pos, lm.idx, lm.ntris, 0,
-                           (passes & WR_PASS_LIGHT_DEBUG) ? 1 : 0, g.ntris, ctx->geom.ws, fc);
-    if ((rc = bin_and_raster(ctx, ms, ctx->geom, false, fc.tile_rank, fc.tile_world)) != WR_OK) return rc;
+                           (passes & WR_PASS_LIGHT_DEBUG) ? 1 : 0, g.ntris, f->geom.ws, fc);
+    if ((rc = bin_and_raster(ctx, f, ms, f->geom, false, fc.tile_rank, fc.tile_world)) != WR_OK) return rc;
     if (prof) WR_HIP(hipEventRecord(ev[3], ms));
-    WR_HIP(hipEventRecord(ctx->ev_geom_done, ms));
+    WR_HIP(hipEventRecord(f->ev_geom_done, ms));
 
     // side stream: fog volume set-up, noise tables, fog raster, march
     FogArgs fa;
     memset(&fa, 0, sizeof(fa));
-    WR_HIP(hipStreamWaitEvent(ss, ctx->ev_geom_done, 0));
+    WR_HIP(hipStreamWaitEvent(ss, f->ev_geom_done, 0));
     if (prof) WR_HIP(hipEventRecord(ev[8], ss));
     if (fog_pass) {
-        hipLaunchKernelGGL(k_setup_small, grid1(fm.ntris), dim3(256), 0, ss, fm.pos, fm.idx, fm.ntris, 1, 1, 0u, ctx->fog.ws, fc);
+        hipLaunchKernelGGL(k_setup_small, grid1(fm.ntris), dim3(256), 0, ss, fm.pos, fm.idx, fm.ntris, 1, 1, 0u, f->fog.ws, fc);
         uint32_t max_entries = 0;
-        fa.tables_noise = plan_noise_tables(ctx, fc, &max_entries);
+        fa.tables_noise = plan_noise_tables(ctx, f, fc, &max_entries);
         if (max_entries)
             hipLaunchKernelGGL(k_fog_tables, dim3((max_entries + 255u) / 256u, 16, 1), dim3(256), 0, ss, fa.tables_noise);
-        fa.fc = fc; fa.ws = ctx->fog.ws; fa.pos = fm.pos; fa.idx = fm.idx; fa.ntris = fm.ntris;
-        fa.depth = ctx->d_depth; fa.color = ctx->d_color; fa.shadow = ctx->d_shadow; fa.tables = ctx->d_tables;
+        fa.fc = fc; fa.ws = f->fog.ws; fa.pos = fm.pos; fa.idx = fm.idx; fa.ntris = fm.ntris;
+        fa.depth = f->d_depth; fa.color = f->d_color; fa.shadow = f->d_shadow; fa.tables = ctx->d_tables;
         fa.counters = ctx->d_counters;
         // the fog workspace has one bin and is not binned, so its bin_count and bin_cursor words
         // are free: they count the march items and the pixels with several fog fragments
-        fa.item_count = ctx->fog.ws.bin_count; fa.item_pixel = ctx->d_fog_pixel; fa.item_ray = ctx->d_fog_ray;
-        fa.item_src = ctx->d_fog_src;
-        fa.multi_count = ctx->fog.ws.bin_cursor; fa.multi_pixel = ctx->d_fog_multi;
+        fa.item_count = f->fog.ws.bin_count; fa.item_pixel = f->d_fog_pixel; fa.item_ray = f->d_fog_ray;
+        fa.item_src = f->d_fog_src;
+        fa.multi_count = f->fog.ws.bin_cursor; fa.multi_pixel = f->d_fog_multi;
         dim3 mg((uint32_t)(((size_t)ctx->W * ctx->H + 63) / 64), 1, 1);
         dim3 fg((uint32_t)(ctx->W + kFogBlock - 1) / kFogBlock, (uint32_t)(ctx->H + kFogBlock - 1) / kFogBlock, 1);
         if (ctx->counting) hipLaunchKernelGGL(k_fog_setup<true>, fg, dim3(1024), 0, ss, fa);
@@ -504,24 +542,24 @@ int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do
         WR_HIP(hipEventRecord(ev[6], ss));
     }
     if (prof) WR_HIP(hipEventRecord(ev[5], ss));
-    WR_HIP(hipEventRecord(ctx->ev_join, ss));
+    WR_HIP(hipEventRecord(f->ev_join, ss));
 
     // main stream: shading (reads the shadow maps)
-    WR_HIP(hipStreamWaitEvent(ms, ctx->ev_shadow_done, 0));
+    WR_HIP(hipStreamWaitEvent(ms, f->ev_shadow_done, 0));
     ShadeArgs sa;
-    sa.fc = fc; sa.ws = ctx->geom.ws; sa.vis = ctx->d_vis; sa.depth = ctx->d_depth; sa.color = ctx->d_color;
+    sa.fc = fc; sa.ws = f->geom.ws; sa.vis = f->d_vis; sa.depth = f->d_depth; sa.color = f->d_color;
     sa.idx = g.idx; sa.tri_mat = g.tri_mat; sa.ntris_geom = g.ntris;
-    sa.v0 = ctx->vout.v0; sa.v1 = ctx->vout.v1; sa.v2 = ctx->vout.v2; sa.v3 = ctx->vout.v3;
+    sa.v0 = f->vout.v0; sa.v1 = f->vout.v1; sa.v2 = f->vout.v2; sa.v3 = f->vout.v3;
     sa.mats = ctx->d_mats; sa.tex = ctx->d_tex; sa.texels = ctx->d_texels; sa.tables = ctx->d_tables;
-    sa.shadow = ctx->d_shadow; sa.counters = ctx->d_counters;
-    sa.bw = ctx->blend;
+    sa.shadow = f->d_shadow; sa.counters = ctx->d_counters;
+    sa.bw = f->blend;
     dim3 pg((uint32_t)(ctx->W + 15) / 16, (uint32_t)(ctx->H + 15) / 16, 1);
     if (ctx->counting) hipLaunchKernelGGL(k_shade<true>, pg, dim3(256), 0, ms, sa);
     else hipLaunchKernelGGL(k_shade<false>, pg, dim3(256), 0, ms, sa);
     // ordered blending of the pixels k_shade flagged: collect, order, shade, blend
     {
-        const RasterWS& ws = ctx->geom.ws;
-        LayerSink ls{ctx->blend.rp_slot, ctx->d_vis, ctx->blend.bin_flag, ctx->blend.lists, ctx->blend.list_count, ctx->blend.cap};
+        const RasterWS& ws = f->geom.ws;
+        LayerSink ls{f->blend.rp_slot, f->d_vis, f->blend.bin_flag, f->blend.lists, f->blend.list_count, f->blend.cap};
         hipLaunchKernelGGL((k_raster<kRasterLayers, 1024>), dim3((uint32_t)(ws.bins_x * ws.bins_y), 1, 1), dim3(1024), 0,
                            ms, ws, ctx->W, ctx->H, (uint32_t*)nullptr, (float*)nullptr, fc.tile_rank, fc.tile_world, ls);
         const size_t npx = (size_t)ctx->W * ctx->H;
@@ -535,7 +573,7 @@ int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do
     if (prof) WR_HIP(hipEventRecord(ev[4], ms));
 
     // main stream: fog colours over the finished geometry colour
-    WR_HIP(hipStreamWaitEvent(ms, ctx->ev_join, 0));
+    WR_HIP(hipStreamWaitEvent(ms, f->ev_join, 0));
     if (fog_pass) {
         hipLaunchKernelGGL(k_fog_blend, dim3(2048), dim3(256), 0, ms, fa);
         if (ctx->counting) hipLaunchKernelGGL(k_fog_multi<true>, dim3(1024), dim3(64), 0, ms, fa);
@@ -548,6 +586,21 @@ int frame_stages(WrContext* ctx, const FrameConsts& fc, uint32_t passes, bool do
     }
     WR_HIP(hipGetLastError());
     return WR_OK;
+}
+
+// Marks the end of a frame's work on its main stream.  With one frame in flight the caller's
+// stream continues after the frame, as if the frame had run there.
+int finish_frame(WrContext* ctx, FrameRes* f) {
+    WR_HIP(hipEventRecord(f->ev_done, f->ms));
+    f->submitted = true;
+    if (ctx->nfr == 1) WR_HIP(hipStreamWaitEvent(ctx->stream, f->ev_done, 0));
+    return WR_OK;
+}
+
+// The set of frame buffers the next frame goes to.
+FrameRes* next_frame(WrContext* ctx) {
+    ctx->cur = (ctx->cur + 1) % ctx->nfr;
+    return &ctx->fr[ctx->cur];
 }
 
 int check_ready(WrContext* ctx, uint32_t passes) {
@@ -588,25 +641,31 @@ int wr_create(const WrConfig* config, WrContext** out_ctx) {
     auto body = [&]() -> int {
         if (config->stream) ctx->stream = (hipStream_t)config->stream;
         else { WR_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
-        for (int f = 0; f < WrContext::kEvFrames; ++f)
-            for (int i = 0; i < WrContext::kEvPerFrame; ++i) WR_HIP(hipEventCreate(&ctx->ev[f][i]));
-        WR_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
-        WR_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-        WR_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-        WR_HIP(hipEventCreateWithFlags(&ctx->ev_shadow_done, hipEventDisableTiming));
-        WR_HIP(hipEventCreateWithFlags(&ctx->ev_geom_done, hipEventDisableTiming));
+        for (int k = 0; k < WrContext::kEvFrames; ++k)
+            for (int i = 0; i < WrContext::kEvPerFrame; ++i) WR_HIP(hipEventCreate(&ctx->ev[k][i]));
+        ctx->nfr = config->frames_in_flight >= 2 ? 2 : 1;
+        for (int k = 0; k < ctx->nfr; ++k) {
+            FrameRes* f = &ctx->fr[k];
+            WR_HIP(hipStreamCreateWithFlags(&f->ms, hipStreamNonBlocking));
+            WR_HIP(hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
+            hipEvent_t* evs[] = {&f->ev_fork, &f->ev_start, &f->ev_join, &f->ev_shadow_done, &f->ev_geom_done, &f->ev_done};
+            for (hipEvent_t* e : evs) WR_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        }
         float tables[768];
         build_tables(tables);
         WR_HIP(hipMalloc(&ctx->d_tables, sizeof(tables)));
         WR_HIP(hipMemcpy(ctx->d_tables, tables, sizeof(tables), hipMemcpyHostToDevice));
         WR_HIP(hipMalloc(&ctx->d_counters, 8 * sizeof(unsigned long long)));
         WR_HIP(hipMemset(ctx->d_counters, 0, 8 * sizeof(unsigned long long)));
-        WR_HIP(hipMalloc(&ctx->d_noise_pool, kNoisePoolEntries * sizeof(float)));
         WR_HIP(hipMalloc(&ctx->d_err, 4 * sizeof(uint32_t)));
         WR_HIP(hipMemset(ctx->d_err, 0, 4 * sizeof(uint32_t)));
         size_t ns = (size_t)6 * S * S;
-        WR_HIP(hipMalloc(&ctx->d_shadow, ns * 4));
-        hipLaunchKernelGGL(k_fill_f32, dim3((uint32_t)((ns + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_shadow, ns, 1.0f);
+        for (int k = 0; k < ctx->nfr; ++k) {
+            FrameRes* f = &ctx->fr[k];
+            WR_HIP(hipMalloc(&f->d_noise_pool, kNoisePoolEntries * sizeof(float)));
+            WR_HIP(hipMalloc(&f->d_shadow, ns * 4));
+            hipLaunchKernelGGL(k_fill_f32, dim3((uint32_t)((ns + 255) / 256)), dim3(256), 0, ctx->stream, f->d_shadow, ns, 1.0f);
+        }
         WR_HIP(hipStreamSynchronize(ctx->stream));
         return alloc_targets(ctx);
     };
@@ -619,17 +678,23 @@ int wr_create(const WrConfig* config, WrContext** out_ctx) {
 void wr_destroy(WrContext* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->cfg.device);
+    for (FrameRes& f : ctx->fr) {
+        if (f.ms) (void)hipStreamSynchronize(f.ms);
+        if (f.side) (void)hipStreamSynchronize(f.side);
+    }
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_scene(ctx);
     free_targets(ctx);
-    dfree(ctx->d_tables); dfree(ctx->d_counters); dfree(ctx->d_err); dfree(ctx->d_shadow); dfree(ctx->d_noise_pool);
-    for (int f = 0; f < WrContext::kEvFrames; ++f)
-        for (int i = 0; i < WrContext::kEvPerFrame; ++i) if (ctx->ev[f][i]) (void)hipEventDestroy(ctx->ev[f][i]);
-    if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-    if (ctx->ev_shadow_done) (void)hipEventDestroy(ctx->ev_shadow_done);
-    if (ctx->ev_geom_done) (void)hipEventDestroy(ctx->ev_geom_done);
+    dfree(ctx->d_tables); dfree(ctx->d_counters); dfree(ctx->d_err);
+    for (int k = 0; k < WrContext::kEvFrames; ++k)
+        for (int i = 0; i < WrContext::kEvPerFrame; ++i) if (ctx->ev[k][i]) (void)hipEventDestroy(ctx->ev[k][i]);
+    for (FrameRes& f : ctx->fr) {
+        dfree(f.d_shadow); dfree(f.d_noise_pool);
+        if (f.ms) (void)hipStreamDestroy(f.ms);
+        if (f.side) (void)hipStreamDestroy(f.side);
+        hipEvent_t evs[] = {f.ev_fork, f.ev_start, f.ev_join, f.ev_shadow_done, f.ev_geom_done, f.ev_done};
+        for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+    }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -639,7 +704,10 @@ int wr_resize(WrContext* ctx, uint32_t width, uint32_t height) {
     if (width == 0 || height == 0) return WR_OK;  // state.rs:576 ignores empty sizes
     if (width > 7168 || height > 7168) return fail(ctx, WR_ERR_INVALID_ARGUMENT, "target larger than 7168");
     WR_HIP(hipSetDevice(ctx->cfg.device));
-    WR_HIP(hipStreamSynchronize(ctx->stream));
+    {
+        int rcs = sync_all(ctx);
+        if (rcs != WR_OK) return rcs;
+    }
     ctx->W = (int)width; ctx->H = (int)height;
     ctx->cfg.width = width; ctx->cfg.height = height;
     ctx->scene_dirty = true;
@@ -714,7 +782,9 @@ int wr_render_frame(WrContext* ctx, const WrCameraUniform* camera, const WrLight
     if (rc != WR_OK) return rc;
     if (ctx->counting) WR_HIP(hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
     FrameConsts fc = make_consts(ctx, camera, light, globals);
-    return frame_stages(ctx, fc, passes, true);
+    FrameRes* f = next_frame(ctx);
+    if ((rc = frame_stages(ctx, f, fc, passes, true)) != WR_OK) return rc;
+    return finish_frame(ctx, f);
 }
 
 int wr_render_batch(WrContext* ctx, const WrCameraUniform* cameras, uint32_t count, const WrLightUniform* light,
@@ -724,12 +794,16 @@ int wr_render_batch(WrContext* ctx, const WrCameraUniform* cameras, uint32_t cou
     if (rc != WR_OK) return rc;
     if (ctx->counting) WR_HIP(hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
     size_t frame_bytes = (size_t)ctx->W * ctx->H * 4;
+    FrameRes* f = next_frame(ctx);
     for (uint32_t i = 0; i < count; ++i) {
         FrameConsts fc = make_consts(ctx, &cameras[i], light, globals);
-        if ((rc = frame_stages(ctx, fc, passes, shadows_every_frame || i == 0)) != WR_OK) return rc;
+        // a batch that reuses the first frame's shadow maps stays on one set of frame buffers
+        if (shadows_every_frame && i > 0) f = next_frame(ctx);
+        if ((rc = frame_stages(ctx, f, fc, passes, shadows_every_frame || i == 0)) != WR_OK) return rc;
         if (device_frames)
-            WR_HIP(hipMemcpyAsync((uint8_t*)device_frames + (size_t)i * frame_bytes, ctx->d_color, frame_bytes,
-                                  hipMemcpyDeviceToDevice, ctx->stream));
+            WR_HIP(hipMemcpyAsync((uint8_t*)device_frames + (size_t)i * frame_bytes, f->d_color, frame_bytes,
+                                  hipMemcpyDeviceToDevice, f->ms));
+        if ((rc = finish_frame(ctx, f)) != WR_OK) return rc;
     }
     return WR_OK;
 }
@@ -737,7 +811,10 @@ int wr_render_batch(WrContext* ctx, const WrCameraUniform* cameras, uint32_t cou
 int wr_sync(WrContext* ctx) {
     if (!ctx) return WR_ERR_INVALID_ARGUMENT;
     WR_HIP(hipSetDevice(ctx->cfg.device));
-    WR_HIP(hipStreamSynchronize(ctx->stream));
+    {
+        int rcs = sync_all(ctx);
+        if (rcs != WR_OK) return rcs;
+    }
     uint32_t e[4] = {0, 0, 0, 0};
     WR_HIP(hipMemcpy(e, ctx->d_err, sizeof(e), hipMemcpyDeviceToHost));
     ctx->stats.geometry_bin_items = e[1];
@@ -759,19 +836,19 @@ static int read_back(WrContext* ctx, void* dst, size_t bytes, const void* src, s
     return WR_OK;
 }
 int wr_read_color(WrContext* ctx, uint8_t* dst, size_t bytes) {
-    return read_back(ctx, dst, bytes, ctx ? ctx->d_color : nullptr, ctx ? (size_t)ctx->W * ctx->H * 4 : 0);
+    return read_back(ctx, dst, bytes, ctx ? ctx->fr[ctx->cur].d_color : nullptr, ctx ? (size_t)ctx->W * ctx->H * 4 : 0);
 }
 int wr_read_depth(WrContext* ctx, float* dst, size_t bytes) {
-    return read_back(ctx, dst, bytes, ctx ? ctx->d_depth : nullptr, ctx ? (size_t)ctx->W * ctx->H * 4 : 0);
+    return read_back(ctx, dst, bytes, ctx ? ctx->fr[ctx->cur].d_depth : nullptr, ctx ? (size_t)ctx->W * ctx->H * 4 : 0);
 }
 int wr_read_visibility(WrContext* ctx, uint32_t* dst, size_t bytes) {
-    return read_back(ctx, dst, bytes, ctx ? ctx->d_vis : nullptr, ctx ? (size_t)ctx->W * ctx->H * 4 : 0);
+    return read_back(ctx, dst, bytes, ctx ? ctx->fr[ctx->cur].d_vis : nullptr, ctx ? (size_t)ctx->W * ctx->H * 4 : 0);
 }
 int wr_read_shadow_map(WrContext* ctx, float* dst, size_t bytes) {
-    return read_back(ctx, dst, bytes, ctx ? ctx->d_shadow : nullptr, ctx ? (size_t)6 * ctx->S * ctx->S * 4 : 0);
+    return read_back(ctx, dst, bytes, ctx ? ctx->fr[ctx->cur].d_shadow : nullptr, ctx ? (size_t)6 * ctx->S * ctx->S * 4 : 0);
 }
 
-void* wr_color_device_ptr(WrContext* ctx) { return ctx ? ctx->d_color : nullptr; }
+void* wr_color_device_ptr(WrContext* ctx) { return ctx ? ctx->fr[ctx->cur].d_color : nullptr; }
 
 int wr_pack_owned_bins(WrContext* ctx, void* device_dst, uint32_t* out_bins) {
     if (!ctx || !device_dst) return fail(ctx, WR_ERR_INVALID_ARGUMENT, "null destination");
@@ -780,8 +857,10 @@ int wr_pack_owned_bins(WrContext* ctx, void* device_dst, uint32_t* out_bins) {
     int world = (int)(ctx->cfg.tile_world ? ctx->cfg.tile_world : 1), rank = (int)ctx->cfg.tile_rank;
     int owned = (nb - rank + world - 1) / world;
     if (out_bins) *out_bins = (uint32_t)owned;
+    FrameRes* f = &ctx->fr[ctx->cur];
+    if (f->submitted) WR_HIP(hipStreamWaitEvent(ctx->stream, f->ev_done, 0));
     if (owned > 0)
-        hipLaunchKernelGGL(k_pack_bins, dim3((uint32_t)owned), dim3(256), 0, ctx->stream, ctx->d_color, (uint32_t*)device_dst,
+        hipLaunchKernelGGL(k_pack_bins, dim3((uint32_t)owned), dim3(256), 0, ctx->stream, f->d_color, (uint32_t*)device_dst,
                            ctx->W, ctx->H, bx, nb, rank, world, 1);
     WR_HIP(hipGetLastError());
     return WR_OK;
@@ -792,8 +871,10 @@ int wr_scatter_bins(WrContext* ctx, const void* device_src, uint32_t rank, uint3
     WR_HIP(hipSetDevice(ctx->cfg.device));
     int bx = (ctx->W + kBin - 1) / kBin, by = (ctx->H + kBin - 1) / kBin, nb = bx * by;
     int owned = (nb - (int)rank + (int)world - 1) / (int)world;
+    FrameRes* f = &ctx->fr[ctx->cur];
+    if (f->submitted) WR_HIP(hipStreamWaitEvent(ctx->stream, f->ev_done, 0));
     if (owned > 0)
-        hipLaunchKernelGGL(k_pack_bins, dim3((uint32_t)owned), dim3(256), 0, ctx->stream, ctx->d_color,
+        hipLaunchKernelGGL(k_pack_bins, dim3((uint32_t)owned), dim3(256), 0, ctx->stream, f->d_color,
                            (uint32_t*)const_cast<void*>(device_src), ctx->W, ctx->H, bx, nb, (int)rank, (int)world, 0);
     WR_HIP(hipGetLastError());
     return WR_OK;
@@ -821,10 +902,10 @@ int wr_get_stats(WrContext* ctx, WrFrameStats* out) {
         // wait for the shadow maps, the frame ends with the fog blend
         const int a[6] = {1, 0, 3, 8, 0, 6}, b[6] = {2, 3, 4, 5, 7, 5};  // shadow, geometry, shade, fog, frame, march
         double ms[6] = {0, 0, 0, 0, 0, 0};
-        for (int f = 0; f < ctx->ev_count; ++f)
+        for (int k = 0; k < ctx->ev_count; ++k)
             for (int i = 0; i < 6; ++i) {
                 float t = 0.0f;
-                WR_HIP(hipEventElapsedTime(&t, ctx->ev[f][a[i]], ctx->ev[f][b[i]]));
+                WR_HIP(hipEventElapsedTime(&t, ctx->ev[k][a[i]], ctx->ev[k][b[i]]));
                 ms[i] += t;
             }
         for (int i = 0; i < 6; ++i) ms[i] /= ctx->ev_count;
@@ -975,7 +1056,8 @@ void wr_camera_fly_update(float pose[5], const float in[5], float speed, float s
 #ifdef WR_DEV
 // Developer build only: copies binning state of the last frame to the host.
 extern "C" int wr_dev_read(WrContext* ctx, int which, void* dst, size_t bytes) {
-    WsAlloc& w = (which & 1) ? ctx->geom : ctx->shadow;
+    FrameRes* f = &ctx->fr[ctx->cur];
+    WsAlloc& w = (which & 1) ? f->geom : f->shadow;
     const RasterWS& ws = w.ws;
     size_t nb = (size_t)ws.bins_x * ws.bins_y * ws.layers;
     size_t nrec = (size_t)ws.layers * ((size_t)ws.slots + ws.ovf_cap);
@@ -987,7 +1069,7 @@ extern "C" int wr_dev_read(WrContext* ctx, int which, void* dst, size_t bytes) {
         case 2: src = ws.bin_offset; have = nb * 4; break;
         case 3: src = ws.bin_items; have = (size_t)ws.items_cap * 4; break;
     }
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)sync_all(ctx);
     if ((which >> 1) == 4) {
         have = sizeof(unsigned long long) * 3 * 40000;
         if (bytes > have) bytes = have;
