@@ -421,24 +421,101 @@ int shadow_stage(WrContext* ctx, FrameRes* f, hipStream_t st, const FrameConsts&
     return bin_and_raster(ctx, f, st, f->shadow, true, 0, 1);
 }
 
-// Chooses which noise levels get a hash table this frame.  Every march sample lies within
-// the fog volume's world box grown by the longest march (30*5 + 10*10 units); a level is
-// tabled when its lattice over that box fits the per-level and pool budgets.  Samples that
-// still fall outside (they cannot, short of non-finite inputs) are evaluated directly.
+// World-space box around the points the fog marches of this frame can sample: the part of the
+// fog model's bounding box surface that faces the camera and lies in the view frustum (where
+// fog fragments, i.e. march origins, can be), each point extended by the longest view march
+// (30 steps of 5 units along its view ray), the whole then extended towards the light by at
+// most the longest light march (10 steps of 10 units), plus a margin.  An estimate is enough:
+// a sample outside a noise table is evaluated directly, with the same result.
+bool fog_sample_bounds(const WrContext* ctx, const FrameConsts& fc, double lo[3], double hi[3]) {
+    const float* a = ctx->fog_aabb;
+    double corner[8][3];
+    for (int c = 0; c < 8; ++c) {
+        const double p[3] = {a[(c & 1) ? 3 : 0], a[(c & 2) ? 4 : 1], a[(c & 4) ? 5 : 2]};
+        for (int r = 0; r < 3; ++r) {
+            corner[c][r] = fc.model_fog[r] * p[0] + fc.model_fog[4 + r] * p[1] + fc.model_fog[8 + r] * p[2] + fc.model_fog[12 + r];
+            if (!(std::fabs(corner[c][r]) < 1e7)) return false;
+        }
+    }
+    static const int faces[6][4] = {{0, 2, 6, 4}, {1, 5, 7, 3}, {0, 4, 5, 1}, {2, 3, 7, 6}, {0, 1, 3, 2}, {4, 6, 7, 5}};
+    double centre[3] = {0, 0, 0};
+    for (int c = 0; c < 8; ++c) for (int r = 0; r < 3; ++r) centre[r] += corner[c][r] / 8.0;
+    for (int r = 0; r < 3; ++r) { lo[r] = 1e300; hi[r] = -1e300; }
+    bool any = false;
+    for (int fi = 0; fi < 6; ++fi) {
+        // faces turned away from the camera produce no fragments (back-face culling); which way
+        // a face looks is judged from the box centre, so the vertex order above does not matter
+        double fc_[3] = {0, 0, 0};
+        for (int k = 0; k < 4; ++k) for (int r = 0; r < 3; ++r) fc_[r] += corner[faces[fi][k]][r] / 4.0;
+        double out_dot = 0.0;
+        for (int r = 0; r < 3; ++r) out_dot += (fc_[r] - centre[r]) * ((double)fc.cam_pos[r] - fc_[r]);
+        if (!(out_dot > 0.0)) continue;
+        // clip the face against the six frustum planes in clip space, carrying world positions
+        struct P { double w[3]; double c[4]; };
+        std::vector<P> poly, next;
+        for (int k = 0; k < 4; ++k) {
+            P q;
+            for (int r = 0; r < 3; ++r) q.w[r] = corner[faces[fi][k]][r];
+            for (int r = 0; r < 4; ++r) q.c[r] = fc.pv[r] * q.w[0] + fc.pv[4 + r] * q.w[1] + fc.pv[8 + r] * q.w[2] + fc.pv[12 + r];
+            poly.push_back(q);
+        }
+        for (int pl = 0; pl < 6 && !poly.empty(); ++pl) {
+            auto dist = [pl](const P& q) {
+                switch (pl) {
+                    case 0: return q.c[3] + q.c[0];
+                    case 1: return q.c[3] - q.c[0];
+                    case 2: return q.c[3] + q.c[1];
+                    case 3: return q.c[3] - q.c[1];
+                    case 4: return q.c[2];
+                    default: return q.c[3] - q.c[2];
+                }
+            };
+            next.clear();
+            for (size_t k = 0; k < poly.size(); ++k) {
+                const P& p0 = poly[k];
+                const P& p1 = poly[(k + 1) % poly.size()];
+                const double d0 = dist(p0), d1 = dist(p1);
+                if (d0 >= 0.0) next.push_back(p0);
+                if ((d0 >= 0.0) != (d1 >= 0.0)) {
+                    const double t = d0 / (d0 - d1);
+                    P q;
+                    for (int r = 0; r < 3; ++r) q.w[r] = p0.w[r] + t * (p1.w[r] - p0.w[r]);
+                    for (int r = 0; r < 4; ++r) q.c[r] = p0.c[r] + t * (p1.c[r] - p0.c[r]);
+                    next.push_back(q);
+                }
+            }
+            poly.swap(next);
+        }
+        for (const P& q : poly) {
+            double d[3], len = 0.0;
+            for (int r = 0; r < 3; ++r) { d[r] = q.w[r] - (double)fc.cam_pos[r]; len += d[r] * d[r]; }
+            len = std::sqrt(len);
+            for (int r = 0; r < 3; ++r) {
+                const double e = len > 0.0 ? q.w[r] + 150.0 * d[r] / len : q.w[r];
+                lo[r] = std::min(lo[r], std::min(q.w[r], e));
+                hi[r] = std::max(hi[r], std::max(q.w[r], e));
+            }
+            any = true;
+        }
+    }
+    if (!any) return false;
+    for (int r = 0; r < 3; ++r) {
+        const double L = fc.light_pos[r];
+        lo[r] = std::min(lo[r], std::max(L, lo[r] - 100.0)) - 3.0;
+        hi[r] = std::max(hi[r], std::min(L, hi[r] + 100.0)) + 3.0;
+    }
+    return true;
+}
+
+// Chooses which noise levels get a hash table this frame: a level is tabled when its lattice
+// over the box of fog_sample_bounds fits the per-level and pool budgets.
 NoiseTables plan_noise_tables(const WrContext* ctx, const FrameRes* f, const FrameConsts& fc, uint32_t* max_entries) {
     NoiseTables nt;
     memset(&nt, 0, sizeof(nt));
     *max_entries = 0;
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (int c = 0; c < 8; ++c) {
-        double p[3] = {ctx->fog_aabb[(c & 1) ? 3 : 0], ctx->fog_aabb[(c & 2) ? 4 : 1], ctx->fog_aabb[(c & 4) ? 5 : 2]};
-        for (int r = 0; r < 3; ++r) {
-            double w = fc.model_fog[r] * p[0] + fc.model_fog[4 + r] * p[1] + fc.model_fog[8 + r] * p[2] + fc.model_fog[12 + r];
-            if (!(std::fabs(w) < 1e7)) return nt;
-            lo[r] = std::min(lo[r], w); hi[r] = std::max(hi[r], w);
-        }
-    }
-    const double grow = 30 * 5.0 + 10 * 10.0 + 2.0;
+    double lo[3], hi[3];
+    if (!fog_sample_bounds(ctx, fc, lo, hi)) return nt;
+    const double grow = 0.0;
     const double drift[3] = {fc.drift_xy, fc.drift_xy, fc.drift_z};
     size_t used = 0;
     for (int k = 0; k < 2; ++k)
