@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--poses", type=int, default=512)
-    ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2],
+    ap.add_argument("--frames-in-flight", type=int, default=3, choices=[1, 2, 3, 4],
                     help="sets of frame buffers the library alternates between (WrConfig.frames_in_flight)")
     args = ap.parse_args()
 

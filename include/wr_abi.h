@@ -123,10 +123,10 @@ typedef struct WrConfig {
     void* stream;
     /* Frames in flight (the reference's surface keeps more than one frame in flight as well,
      * state.rs:631,806).  0 or 1: a frame's work is complete, as seen from `stream`, before
-     * anything queued on `stream` afterwards.  2: consecutive frames use alternate sets of frame
-     * buffers and overlap on the device; a frame's results are complete after wr_sync (every
-     * wr_read_* and wr_get_stats syncs), and read-back / wr_color_device_ptr refer to the most
-     * recently submitted frame. */
+     * anything queued on `stream` afterwards.  2 to 4: consecutive frames rotate through that
+     * many sets of frame buffers (about 1.1 GB each at 1080p) and overlap on the device; a
+     * frame's results are complete after wr_sync (every wr_read_* and wr_get_stats syncs), and
+     * read-back / wr_color_device_ptr refer to the most recently submitted frame. */
     uint32_t frames_in_flight;
     uint32_t reserved;
 } WrConfig;

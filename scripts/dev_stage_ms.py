@@ -6,7 +6,7 @@ for lib in libs:
     env = dict(os.environ)
     if lib:
         env["WR_HIP_LIBRARY"] = os.path.abspath(lib)
-    p = subprocess.run([sys.executable, "bench.py", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--tex-size", "256"],
+    p = subprocess.run([sys.executable, "bench.py", "--steps", "40", "--warmup", "3", "--no-cpu-baseline", "--tex-size", "256"],
                        env=env, capture_output=True, text=True)
     line = [l for l in p.stdout.splitlines() if l.startswith("{")]
     if not line:

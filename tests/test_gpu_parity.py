@@ -251,8 +251,9 @@ def test_fog_volume_with_overlapping_parts(tiny_scene):
     assert g["counters"]["fog_fragments"] > g1["counters"]["fog_fragments"]  # the slab added fragments
 
 
-def test_two_frames_in_flight_match_one(small_scene):
-    """Consecutive frames on alternate sets of frame buffers, overlapping on the device, give
+@pytest.mark.parametrize("in_flight", [2, 3])
+def test_frames_in_flight_match_one(small_scene, in_flight):
+    """Consecutive frames on rotating sets of frame buffers, overlapping on the device, give
     the same pixels as one frame at a time; the light moves between frames, so every frame
     needs its own shadow maps."""
     import torch
@@ -268,7 +269,7 @@ def test_two_frames_in_flight_match_one(small_scene):
         one.render_frame(c, l, g, abi.PASS_ALL)
         ref.append((one.read_color(), one.read_depth(), one.read_shadow_map()))
     one.close()
-    two = abi.Renderer(w, h, s, frames_in_flight=2)
+    two = abi.Renderer(w, h, s, frames_in_flight=in_flight)
     two.upload_scene(small_scene)
     for n in (2, 3, 5):  # submit n frames back to back, then look at the last one
         for c, l, g in list(zip(cams, lights, globs))[:n]:

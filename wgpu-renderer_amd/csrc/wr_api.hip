@@ -63,9 +63,9 @@ struct WsAlloc {
 
 }  // namespace
 
-// Everything one frame in flight writes: with two of these, consecutive frames use alternate
-// sets (and their own pair of streams), so the early, latency-bound stages of one frame run
-// under the fog march of the frame before it.
+// Everything one frame in flight writes.  With several of these, consecutive frames rotate
+// through the sets (each with its own pair of streams), so the early, latency-bound stages of
+// one frame run under the fog march of the frames before it.
 struct FrameRes {
     // ms: geometry pass, shading, fog blend.  ss: shadow pass, then (once the geometry depth
     // exists) the fog pass up to and including the march, next to the shading kernels.
@@ -107,7 +107,7 @@ struct WrContext {
     float* d_tables = nullptr;
     float fog_aabb[6] = {0, 0, 0, 0, 0, 0};  // fog model bounds in model space (min xyz, max xyz)
 
-    static constexpr int kMaxFrames = 2;
+    static constexpr int kMaxFrames = 4;
     FrameRes fr[kMaxFrames];
     int nfr = 1;   // frames in flight (WrConfig.frames_in_flight)
     int cur = 0;   // the set the most recent frame was submitted to
@@ -720,7 +720,7 @@ int wr_create(const WrConfig* config, WrContext** out_ctx) {
         else { WR_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
         for (int k = 0; k < WrContext::kEvFrames; ++k)
             for (int i = 0; i < WrContext::kEvPerFrame; ++i) WR_HIP(hipEventCreate(&ctx->ev[k][i]));
-        ctx->nfr = config->frames_in_flight >= 2 ? 2 : 1;
+        ctx->nfr = (int)std::min<uint32_t>(std::max<uint32_t>(config->frames_in_flight, 1u), (uint32_t)WrContext::kMaxFrames);
         for (int k = 0; k < ctx->nfr; ++k) {
             FrameRes* f = &ctx->fr[k];
             WR_HIP(hipStreamCreateWithFlags(&f->ms, hipStreamNonBlocking));
