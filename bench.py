@@ -41,8 +41,10 @@ PEAK_FP32_TFLOPS = 157.3   # MI355X f32 vector peak = dense f32 matrix peak (MI3
 PEAK_HBM_GBS = 8000.0
 # HBM bytes of one k_fog_march launch on the default frame, from the rocprofv3 PMC passes kept
 # in profiles/ (FETCH_SIZE doubled as the gfx950 note prescribes, plus WRITE_SIZE); None until
-# such a pass has been recorded for the current kernel.
-FOG_MARCH_HBM_BYTES = None
+# such a pass has been recorded for the current kernel.  (Algorithmic bytes of a launch: 20 B
+# read + 16 B written per work item = 24 MB; the rest is the 9 MB of noise tables and the shadow
+# map taps, re-fetched by the eight L2s.)
+FOG_MARCH_HBM_BYTES = (2 * 22460 + 10420) * 1024  # profiles/r01_v3_pmc_hbm.txt
 
 
 def build_scene(args):
@@ -91,8 +93,8 @@ def cpu_baseline(sc, cam, light, glob, passes, W, H, S, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=["frame", "posebatch", "tiles4k"], default="frame")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -224,6 +226,7 @@ def main():
             "traffic": FOG_MARCH_HBM_BYTES if default_frame else None,
             "launch_ms": st.ms_fog_march,
             "launches_averaged": int(st.profiled_frames),
+            "concurrency": f"the kernel shares the device with the other stages of up to {in_flight} frames in flight",
             "flop_per_launch": fog_flops,
         }
         stage_ms = {"shadow": st.ms_shadow, "geometry": st.ms_geometry, "shade": st.ms_shade, "fog": st.ms_fog}
