@@ -245,6 +245,7 @@ def main():
                 "sample": f"1 full frame of the same workload ({W}x{H}, shadows+fog) on the CPU restatement in oracle/ "
                           f"(reference wgpu-on-lavapipe path not buildable offline); {cdt:.2f} s",
                 "fog_noise_evals": int(ccnt["fog_noise_evals"]),
+                "fog_noise_evals_unused": int(ccnt["fog_noise_evals_unused"]),
             }
         out = {
             "metric": "frames/sec Sponza 1080p shadows+fog" if args.workload == "frame" else f"frames/sec {args.workload}",

@@ -154,6 +154,7 @@ float o_sin(float x) {
 // ------------------------------------------------------------------------- noise.wgsl
 struct Counters {
     uint64_t fog_fragments = 0, fog_noise_evals = 0, shaded_fragments = 0, blended_lt1 = 0;
+    uint64_t fog_noise_evals_unused = 0;  // of fog_noise_evals: light marches of fog points in shadow (result never read)
 };
 
 // noise.wgsl:3-5
@@ -687,7 +688,9 @@ V4 fs_fog(const Scene& sc, const float* depth_tex, V3 origin, float frag_z, int 
     V3 to_light = F.light_pos - fog_end;
     float max_light_dist = length3(to_light);
     V3 light_direction = to_light / max_light_dist;
+    const uint64_t evals_before_light_march = cnt.fog_noise_evals;
     V2 lm = ray_march(F, fog_end, light_direction, max_light_dist, 10, 10.0f, 3.0f, cnt);
+    const uint64_t light_march_evals = cnt.fog_noise_evals - evals_before_light_march;
     float occlusion = lm.x;
     V3 fog_position = origin + direction * fog_depth;
     float light_dist = length3(F.light_pos - fog_position);
@@ -700,6 +703,8 @@ V4 fs_fog(const Scene& sc, const float* depth_tex, V3 origin, float frag_z, int 
         float att = 1.0f / (1.0f + light_dist * light_dist);
         V3 lrgb = v3(F.light_color.x, F.light_color.y, F.light_color.z);
         radiance = (((lrgb * F.light_color.w) * att) * in_light) * (1.0f - occlusion);
+    } else {
+        cnt.fog_noise_evals_unused += light_march_evals;
     }
     V3 result = ambient + radiance;
     result = result / (result + v3(1, 1, 1));
@@ -948,6 +953,7 @@ void render(Oracle& o, const WrCameraUniform* cam, const WrLightUniform* light, 
     for (const Counters& c : tcnt) {
         o.cnt.fog_fragments += c.fog_fragments;
         o.cnt.fog_noise_evals += c.fog_noise_evals;
+        o.cnt.fog_noise_evals_unused += c.fog_noise_evals_unused;
         o.cnt.shaded_fragments += c.shaded_fragments;
         o.cnt.blended_lt1 += c.blended_lt1;
     }
@@ -1009,7 +1015,7 @@ const float* wro_shadow(void* p) { return ((Oracle*)p)->shadow.data(); }
 void wro_counters(void* p, uint64_t out[8]) {
     Oracle* o = (Oracle*)p;
     out[0] = o->cnt.fog_fragments; out[1] = o->cnt.fog_noise_evals; out[2] = o->cnt.shaded_fragments;
-    out[3] = o->cnt.blended_lt1; out[4] = o->n_subtris_geom; out[5] = o->n_subtris_shadow; out[6] = 0; out[7] = 0;
+    out[3] = o->cnt.blended_lt1; out[4] = o->n_subtris_geom; out[5] = o->n_subtris_shadow; out[6] = o->cnt.fog_noise_evals_unused; out[7] = 0;
 }
 
 // ---- unit functions for known-answer tests

@@ -126,4 +126,5 @@ class Oracle:
         out = (C.c_uint64 * 8)()
         self.L.wro_counters(self.h, out)
         return dict(fog_fragments=out[0], fog_noise_evals=out[1], shaded_fragments=out[2], blended_lt1=out[3],
-                    geometry_subtriangles=out[4], shadow_subtriangles=out[5])
+                    geometry_subtriangles=out[4], shadow_subtriangles=out[5],
+                    fog_noise_evals_unused=out[6])

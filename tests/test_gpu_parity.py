@@ -53,6 +53,13 @@ def render_oracle(sc, cam, light, glob, passes, w, h, s, threads=16):
     return out
 
 
+def live_evals(o):
+    """fog_noise evaluations whose result reaches the frame: the oracle runs every march of
+    fog.wgsl and counts separately the light marches of fog points in shadow, whose result is
+    never read; the GPU path does not run those."""
+    return o["counters"]["fog_noise_evals"] - o["counters"]["fog_noise_evals_unused"]
+
+
 def assert_parity(g, o, exact=True):
     m = compare(o["vis"], g["vis"], o["color"], g["color"])
     assert m["id_match"] >= ID_MATCH_MIN and m["id_mismatch_off_edge"] == 0, m
@@ -79,7 +86,7 @@ def test_all_passes_small_scene(small_scene):
     assert_parity(g, o)
     # executed march steps are integer work: must agree exactly
     assert g["counters"]["fog_fragments"] == o["counters"]["fog_fragments"] > 0
-    assert g["counters"]["fog_noise_evals"] == o["counters"]["fog_noise_evals"] > 0
+    assert g["counters"]["fog_noise_evals"] == live_evals(o) > 0
     assert o["counters"]["blended_lt1"] > 0  # the ordered-blend path was exercised
 
 
@@ -246,7 +253,7 @@ def test_fog_volume_with_overlapping_parts(tiny_scene):
         assert_parity(g, o)
         assert np.array_equal(g["color"], o["color"])
         assert g["counters"]["fog_fragments"] == o["counters"]["fog_fragments"] > 0
-        assert g["counters"]["fog_noise_evals"] == o["counters"]["fog_noise_evals"]
+        assert g["counters"]["fog_noise_evals"] == live_evals(o)
     g1 = render_gpu(tiny_scene, cam, light, glob, abi.PASS_ALL, w, h, s, counting=True)
     assert g["counters"]["fog_fragments"] > g1["counters"]["fog_fragments"]  # the slab added fragments
 
@@ -398,7 +405,7 @@ def test_full_size_frame_against_oracle(full_scene):
     g = render_gpu(full_scene, cam, light, glob, abi.PASS_ALL, w, h, s, counting=True)
     o = render_oracle(full_scene, cam, light, glob, abi.PASS_ALL, w, h, s, threads=16)
     assert_parity(g, o)
-    assert g["counters"]["fog_noise_evals"] == o["counters"]["fog_noise_evals"]
+    assert g["counters"]["fog_noise_evals"] == live_evals(o)
 
 
 def test_full_size_properties(full_scene):

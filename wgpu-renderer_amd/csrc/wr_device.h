@@ -735,12 +735,6 @@ WR_HD V4 fog_march_shade(const FrameConsts& fc, const ShadowMap& sm, const Noise
     V2 fm = ray_march(fc, nt, origin, direction, max_fog_depth, 30, 5.0f, 2.0f, evals);
     float fog_density = fm.x, fog_depth = fm.y;
     V3 fog_end = origin + direction * fog_depth;
-    V3 to_light = lp - fog_end;
-    float max_light_dist = length3(to_light);
-    V3 light_direction = to_light / max_light_dist;
-    V2 lm = ray_march(fc, nt, fog_end, light_direction, max_light_dist, 10, 10.0f, 3.0f, evals);
-    float occlusion = lm.x;
-
     V3 fog_position = origin + direction * fog_depth;
     float light_dist = length3(lp - fog_position);
     float bc = mixf(0.5f, 0.1f, fog_density);
@@ -749,6 +743,13 @@ WR_HD V4 fog_march_shade(const FrameConsts& fc, const ShadowMap& sm, const Noise
     V3 radiance = v3(0.0f, 0.0f, 0.0f);
     float in_light = sample_direct_light(fc, sm, V4{fog_position.x, fog_position.y, fog_position.z, 1.0f});
     if (in_light > 0.0f) {
+        // The light march (fog.wgsl:150-159) only feeds `occlusion`, which only this branch
+        // reads: a fog point in shadow does not need it, and it is not run for one.
+        V3 to_light = lp - fog_end;
+        float max_light_dist = length3(to_light);
+        V3 light_direction = to_light / max_light_dist;
+        V2 lm = ray_march(fc, nt, fog_end, light_direction, max_light_dist, 10, 10.0f, 3.0f, evals);
+        float occlusion = lm.x;
         float att = 1.0f / (1.0f + light_dist * light_dist);
         radiance = (((v3(fc.light_color[0], fc.light_color[1], fc.light_color[2]) * fc.light_color[3]) * att) * in_light) * (1.0f - occlusion);
     }
