@@ -251,6 +251,29 @@ int wr_set_profiling(WrContext* ctx, int enabled);
 int wr_set_counting(WrContext* ctx, int enabled);
 int wr_get_stats(WrContext* ctx, WrFrameStats* out);
 
+/* ------------------------------------------------------------------ GLB import (host only)
+ *
+ * Replaces load_model_gltf (resources.rs:17-136) and Mesh::from_gltf (mesh.rs:13-112), with
+ * their quirks: one mesh per primitive in document order, node transforms ignored,
+ * tangent = TANGENT.xyz * w, bitangent = normal x tangent, NaN tangents without TANGENT,
+ * missing texture slots fall back to image 0, RGB padded to RGBA, base colour sRGB and the
+ * other two maps linear, primitive.material defaults to 0.  Embedded 8-bit PNG images are
+ * decoded; JPEG, 16-bit and grey images return WR_ERR_UNSUPPORTED (the reference panics on the
+ * last two, resources.rs:51,138-151).  Parsing touches no device. */
+typedef struct WrGlb WrGlb;
+int wr_glb_parse(const void* data, size_t bytes, WrGlb** out, char* err, size_t err_cap);
+int wr_glb_load_file(const char* path, WrGlb** out, char* err, size_t err_cap);
+void wr_glb_free(WrGlb* glb);
+void wr_glb_counts(const WrGlb* glb, uint32_t* meshes, uint32_t* materials, uint32_t* textures);
+/* Pointers stay valid until wr_glb_free.  Material texture ids index wr_glb_texture. */
+int wr_glb_mesh(const WrGlb* glb, uint32_t i, const WrModelVertex** vertices, uint32_t* vertex_count,
+                const uint32_t** indices, uint32_t* index_count, uint32_t* material);
+int wr_glb_texture(const WrGlb* glb, uint32_t i, const uint8_t** rgba8, uint32_t* width, uint32_t* height, int* srgb);
+int wr_glb_material(const WrGlb* glb, uint32_t i, uint32_t* base, uint32_t* normal, uint32_t* mr,
+                    float* metallic, float* roughness);
+/* The upload sequence of load_model_gltf: textures, materials, then meshes in draw order. */
+int wr_upload_glb(WrContext* ctx, uint32_t model, const WrGlb* glb);
+
 /* ------------------------------------------------------------------ host scene math
  * The Rust host keeps these (src/core/camera.rs, light.rs, instance.rs); they are
  * provided so that a C/C++/Python host produces the same uniform bytes. */

@@ -299,6 +299,40 @@ def test_frames_in_flight_match_one(small_scene, in_flight):
     two.close()
 
 
+def test_scene_uploaded_through_the_native_glb_importer(tmp_path):
+    """wr_upload_glb (C++ importer) and the Python loader + wr_upload_* give the same frame."""
+    from test_abi_and_host import _synthetic_glb
+    from wgpu_renderer_amd import gltf_loader
+    w, h, s = 200, 120, 64
+    glb, _ = _synthetic_glb(np.random.default_rng(5), True)
+    p = tmp_path / "s.glb"
+    p.write_bytes(glb)
+    model, textures = gltf_loader.load_glb(str(p))
+    cube = scene.cube_model()
+    inst = abi.instance_raw((0.0, 0.0, -6.0), (1, 0, 0, 0), (2.0, 2.0, 2.0))
+    fog_inst = abi.instance_raw((0.0, -50.0, 0.0), (1, 0, 0, 0), (10.0, 10.0, 10.0))
+    cam = abi.camera_uniform((0.0, 0.0, 0.0), 0.0, -90.0, 55.0, w, h)
+    light = abi.light_uniform((1.0, 3.0, 0.0), (1.0, 0.9, 0.8, 50.0))
+    glob = abi.global_uniforms(1.5, 1)
+    sc = scene.Scene(textures, model, cube, scene.cube_model(), inst, fog_inst)
+    ref = render_gpu(sc, cam, light, glob, abi.PASS_ALL, w, h, s)
+    assert (ref["vis"] != 0xFFFFFFFF).mean() > 0.02
+    o = render_oracle(sc, cam, light, glob, abi.PASS_ALL, w, h, s, threads=2)
+    assert_parity(ref, o)
+    r = abi.Renderer(w, h, s)
+    g = abi.Glb(data=glb)
+    r.upload_glb(abi.MODEL_GEOMETRY, g)
+    g.close()
+    r.set_instance(abi.MODEL_GEOMETRY, inst)
+    for mesh in cube.meshes:
+        r.upload_mesh(abi.MODEL_FOG_VOLUME, mesh.vertices, mesh.indices, mesh.material)
+        r.upload_mesh(abi.MODEL_LIGHT_MARKER, mesh.vertices, mesh.indices, mesh.material)
+    r.set_instance(abi.MODEL_FOG_VOLUME, fog_inst)
+    r.render_frame(cam, light, glob, abi.PASS_ALL)
+    assert np.array_equal(r.read_color(), ref["color"]) and np.array_equal(r.read_visibility(), ref["vis"])
+    r.close()
+
+
 def test_draw_orders_give_different_images():
     w, h, s = 160, 120, 64
     cam = abi.camera_uniform((0.0, 0.0, 500.0), 0.0, -90.0, 55.0, w, h)

@@ -122,6 +122,14 @@ SYMBOLS = {
     "wr_color_device_ptr": (_P, [_P]),
     "wr_pack_owned_bins": (C.c_int, [_P, _P, C.POINTER(C.c_uint32)]),
     "wr_scatter_bins": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32]),
+    "wr_glb_parse": (C.c_int, [_P, C.c_size_t, C.POINTER(_P), C.c_char_p, C.c_size_t]),
+    "wr_glb_load_file": (C.c_int, [C.c_char_p, C.POINTER(_P), C.c_char_p, C.c_size_t]),
+    "wr_glb_free": (None, [_P]),
+    "wr_glb_counts": (None, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "wr_glb_mesh": (C.c_int, [_P, C.c_uint32, C.POINTER(_P), C.POINTER(C.c_uint32), C.POINTER(_P), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "wr_glb_texture": (C.c_int, [_P, C.c_uint32, C.POINTER(_P), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
+    "wr_glb_material": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "wr_upload_glb": (C.c_int, [_P, C.c_uint32, _P]),
     "wr_set_profiling": (C.c_int, [_P, C.c_int]),
     "wr_set_counting": (C.c_int, [_P, C.c_int]),
     "wr_get_stats": (C.c_int, [_P, C.POINTER(FrameStats)]),
@@ -201,6 +209,64 @@ def global_uniforms(time: float, use_shadowmaps: int) -> GlobalUniforms:
     return GlobalUniforms(float(time), 0, int(use_shadowmaps), 0)
 
 
+class Glb:
+    """A GLB file parsed by the library's C++ importer (wr_glb_*): the meshes, textures and
+    materials load_model_gltf (resources.rs:17-136) would create, as numpy views."""
+
+    def __init__(self, data: Optional[bytes] = None, path: Optional[str] = None):
+        self.lib = load_library()
+        h = _P()
+        err = C.create_string_buffer(512)
+        if path is not None:
+            rc = self.lib.wr_glb_load_file(path.encode(), C.byref(h), err, len(err))
+        else:
+            rc = self.lib.wr_glb_parse(data, len(data), C.byref(h), err, len(err))
+        if rc != WR_OK:
+            raise WrError(rc, err.value.decode())
+        self.h = h
+        n = [C.c_uint32() for _ in range(3)]
+        self.lib.wr_glb_counts(h, *[C.byref(x) for x in n])
+        self.mesh_count, self.material_count, self.texture_count = (int(x.value) for x in n)
+
+    def mesh(self, i: int):
+        v, idx = _P(), _P()
+        nv, ni, mat = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        rc = self.lib.wr_glb_mesh(self.h, i, C.byref(v), C.byref(nv), C.byref(idx), C.byref(ni), C.byref(mat))
+        if rc != WR_OK:
+            raise WrError(rc, "bad mesh index")
+        va = np.ctypeslib.as_array(C.cast(v, C.POINTER(C.c_float)), (nv.value, 14)).copy() if nv.value else np.zeros((0, 14), np.float32)
+        ia = np.ctypeslib.as_array(C.cast(idx, C.POINTER(C.c_uint32)), (ni.value,)).copy() if ni.value else np.zeros(0, np.uint32)
+        return va, ia, int(mat.value)
+
+    def texture(self, i: int):
+        px = _P()
+        w, h, srgb = C.c_uint32(), C.c_uint32(), C.c_int()
+        rc = self.lib.wr_glb_texture(self.h, i, C.byref(px), C.byref(w), C.byref(h), C.byref(srgb))
+        if rc != WR_OK:
+            raise WrError(rc, "bad texture index")
+        a = np.ctypeslib.as_array(C.cast(px, C.POINTER(C.c_uint8)), (h.value, w.value, 4)).copy()
+        return a, bool(srgb.value)
+
+    def material(self, i: int):
+        b, n, m = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        met, rough = C.c_float(), C.c_float()
+        rc = self.lib.wr_glb_material(self.h, i, C.byref(b), C.byref(n), C.byref(m), C.byref(met), C.byref(rough))
+        if rc != WR_OK:
+            raise WrError(rc, "bad material index")
+        return int(b.value), int(n.value), int(m.value), float(met.value), float(rough.value)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.wr_glb_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Renderer:
     """One wr context (one GPU, one stream): the object a host keeps where the reference
     keeps its wgpu Device/Queue/pipelines (state.rs:30-66)."""
@@ -274,6 +340,10 @@ class Renderer:
     # ---- frames
     def render_frame(self, camera: CameraUniform, light: LightUniform, globals_: GlobalUniforms, passes: int):
         self._check(self.lib.wr_render_frame(self.h, C.byref(camera), C.byref(light), C.byref(globals_), passes))
+
+    def upload_glb(self, model: int, glb: "Glb"):
+        """load_model_gltf's uploads for one model: textures, materials, meshes in draw order."""
+        self._check(self.lib.wr_upload_glb(self.h, model, glb.h))
 
     def render_batch(self, cameras: Sequence[CameraUniform], light, globals_, passes, shadows_every_frame=False,
                      device_frames: Optional[int] = None):
