@@ -1,20 +1,24 @@
 // wr_kernels.h -- gfx950 kernels of the render path.
 //
-// Frame structure (one HIP stream, kernels in this order):
-//   shadow   : k_vs_shadow -> k_setup<true> (set-up + bin counts) -> k_scan -> k_bin_fill
-//              -> k_raster<true>            (6 cube faces as grid.y "layers")
-//   geometry : k_vs_geometry -> k_setup<false> (+ k_setup_small for the light marker)
-//              -> k_scan -> k_bin_fill -> k_raster<false>   (visibility + depth buffers)
-//   shade    : k_shade -> k_raster<layers> -> k_resolve -> k_shade_frags -> k_blend
+// Frame structure (kernels of one frame; the host runs the shadow pass and the fog pass up to
+// the march on a side stream, see frame_stages in wr_api.hip):
+//   shadow   : k_vs_shadow -> k_setup<true> (set-up + bin counts) -> k_setup_clip<true> ->
+//              k_scan -> k_bin_fill -> k_raster<kRasterShadow>   (6 cube faces as grid.y "layers")
+//   geometry : k_vs_geometry -> k_setup<false> -> k_setup_clip<false> (+ k_setup_small for the
+//              light marker) -> k_scan -> k_bin_fill -> k_raster<kRasterColor>
+//              (visibility + depth buffers)
+//   shade    : k_shade -> k_raster<kRasterLayers> -> k_resolve -> k_replay_slow ->
+//              k_shade_frags -> k_blend
 //              (deferred pbr.wgsl fragment stage; ordered blending of translucent fronts)
-//   fog      : k_setup_small(fog) -> k_fog_setup -> k_fog_march   (fog.wgsl fragment stage)
+//   fog      : k_setup_small(fog) -> k_fog_tables -> k_fog_setup -> k_fog_march ->
+//              k_fog_blend (+ k_fog_multi)                        (fog.wgsl fragment stage)
 //
 // The rasteriser is tile-binned: the target is cut into 64x64-pixel bins, every set-up
-// triangle is appended to the list of each bin it can touch, and one 256-thread workgroup
-// per bin resolves visibility in an LDS tile (64-bit keys: depth bits << 32 | triangle id,
-// combined with LDS atomic-min), then writes the tile out once with coalesced stores.
-// Within a workgroup a wavefront takes one triangle at a time and its 64 lanes test one
-// 8x8 pixel block per step, so the triangle record is wave-uniform (scalar loads).
+// triangle is appended to the list of each bin it can touch, and one workgroup per bin
+// resolves visibility in an LDS tile (64-bit keys: depth bits << 32 | triangle id, combined
+// with LDS atomic-min), then writes the tile out once with coalesced stores.  Small triangles
+// are rasterised one per lane; a large one is taken by a whole wavefront, whose 64 lanes test
+// one 8x8 pixel block per step against a wave-uniform record held in scalar registers.
 #pragma once
 
 #include "wr_device.h"
