@@ -211,6 +211,22 @@ def main():
     st = r.stats()
     r.set_profiling(False)
 
+    # The same kernel with one frame at a time (its launches then overlap only this frame's
+    # shading kernels), outside the timed region: how fast the march runs when it does not
+    # share the device with the marches of the neighbouring frames.
+    march_alone_ms = None
+    if rank == 0 and args.workload == "frame" and in_flight > 1:
+        r1 = abi.Renderer(W, H, S, device=local_rank, frames_in_flight=1)
+        r1.upload_scene(sc)
+        for i in range(3):
+            r1.render_frame(cam, light, glob, passes)
+        r1.sync()
+        r1.set_profiling(True)
+        for i in range(20):
+            r1.render_frame(cam, light, glob, passes)
+        march_alone_ms = float(r1.stats().ms_fog_march)
+        r1.close()
+
     frames_per_step = 1 if args.workload != "tiles4k" else 1.0 / world  # tiles: all ranks share one frame
     total_frames = args.steps * world * frames_per_step
     fps = total_frames / dt
@@ -233,7 +249,12 @@ def main():
             "traffic": FOG_MARCH_HBM_BYTES if default_frame else None,
             "launch_ms": st.ms_fog_march,
             "launches_averaged": int(st.profiled_frames),
-            "concurrency": f"the kernel shares the device with the other stages of up to {in_flight} frames in flight",
+            "concurrency": f"launches of up to {in_flight} frames in flight overlap each other and the other stages, which stretches "
+                           "each launch; one_frame_in_flight is the same kernel measured after the timed region with one frame at a time",
+            "one_frame_in_flight": None if not march_alone_ms else {
+                "launch_ms": march_alone_ms,
+                "achieved": fog_flops / (march_alone_ms * 1e-3) / 1e12,
+                "frac": fog_flops / (march_alone_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS},
             "flop_per_launch": fog_flops,
         }
         stage_ms = {"shadow": st.ms_shadow, "geometry": st.ms_geometry, "shade": st.ms_shade, "fog": st.ms_fog}
