@@ -546,11 +546,7 @@ WR_HD V4 fs_pbr(const FrameConsts& fc, const ShadowMap& sm, const uint32_t* texe
     float light_dist = length3(lp - v3(in.wpos.x, in.wpos.y, in.wpos.z));
     float att = 1.0f / (1.0f + light_dist * light_dist);
     V3 direct = (v3(fc.light_color[0], fc.light_color[1], fc.light_color[2]) * fc.light_color[3]) * att;
-#if defined(WR_ABLATE) && (WR_ABLATE & 2)
-    float in_light = 0.64f;
-#else
     float in_light = sample_direct_light(fc, sm, in.wpos);
-#endif
     if (in_light > 0.0f) {
         V3 view_dir = normalize3(in.tview - in.tpos);
         V3 half_dir = normalize3(view_dir + light_dir);

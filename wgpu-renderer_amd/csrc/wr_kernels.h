@@ -584,12 +584,6 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
                     wanted = ((cols * 0x0101010101010101ull) & rows & s_fmask) != 0ull;
                 }
             }
-#if defined(WR_ABLATE) && (WR_ABLATE & 16)
-            if (MODE == kRasterLayers && fw <= 64 * 256 && fh <= 64 * 256 && (x1 - x0 + 1) * (y1 - y0 + 1) <= WR_RASTER_LANE_AREA) wanted = false;
-#endif
-#if defined(WR_ABLATE) && (WR_ABLATE & 32)
-            if (MODE == kRasterLayers && !(fw <= 64 * 256 && fh <= 64 * 256 && (x1 - x0 + 1) * (y1 - y0 + 1) <= WR_RASTER_LANE_AREA)) wanted = false;
-#endif
             if (!wanted) {
             } else if (fw <= 64 * 256 && fh <= 64 * 256 && (x1 - x0 + 1) * (y1 - y0 + 1) <= WR_RASTER_LANE_AREA) {
                 // The triangle's vertices span at most 64x64 pixels, so every edge function
@@ -873,11 +867,7 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
             // the front-most fragment is not opaque: this pixel's colour depends on draw order;
             // flag it for the ordered-blend kernels
             if (COUNT) atomicAdd(&a.counters[3], 1ull);
-#if defined(WR_ABLATE) && (WR_ABLATE & 1)
-            a.color[pi] = blend_pack(ct, 0xFF000000u, src, true);
-#else
             flagged = true;
-#endif
         }
     }
     if (!__syncthreads_or(flagged ? 1 : 0)) {
