@@ -31,6 +31,10 @@ static_assert(sizeof(WrCameraUniform) == 224, "CameraUniform layout (camera.rs:1
 static_assert(sizeof(WrLightUniform) == 416, "LightUniform layout (light.rs:11-18)");
 static_assert(sizeof(WrGlobalUniforms) == 16, "GlobalUniforms layout (state.rs:21-28)");
 static_assert(sizeof(WrMaterialUniform) == 16, "MaterialUniform layout (material.rs:13-18)");
+#ifndef WR_COLOR_RASTER_THREADS
+#define WR_COLOR_RASTER_THREADS 256
+#endif
+constexpr int kColorRasterThreads = WR_COLOR_RASTER_THREADS;
 constexpr size_t kNoiseLevelEntries = 2u << 20;  // largest hash table of one noise level
 constexpr size_t kNoisePoolEntries = 4u << 20;   // all levels together (16 MB)
 static_assert(sizeof(FrameConsts) < 3072, "FrameConsts must fit the kernel argument segment");
@@ -394,14 +398,14 @@ dim3 grid1(uint32_t n, uint32_t layers = 1) { return dim3((n + 255u) / 256u, lay
 int bin_and_raster(WrContext* ctx, FrameRes* f, hipStream_t st, WsAlloc& w, bool shadow, int tr, int tw) {
     RasterWS& ws = w.ws;
     uint32_t nrec = ws.slots + ws.ovf_cap;
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, ws);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(kScanThreads), 0, st, ws);
     hipLaunchKernelGGL(k_bin_fill, grid1(nrec, ws.layers), dim3(256), 0, st, ws, tr, tw);
     dim3 g((uint32_t)(ws.bins_x * ws.bins_y), (uint32_t)ws.layers, 1);
     if (shadow)
         hipLaunchKernelGGL((k_raster<kRasterShadow, 256>), g, dim3(256), 0, st, ws, ctx->S, ctx->S, (uint32_t*)nullptr,
                            f->d_shadow, 0, 1, LayerSink{});
     else
-        hipLaunchKernelGGL((k_raster<kRasterColor, 1024>), g, dim3(1024), 0, st, ws, ctx->W, ctx->H, f->d_vis,
+        hipLaunchKernelGGL((k_raster<kRasterColor, kColorRasterThreads>), g, dim3(kColorRasterThreads), 0, st, ws, ctx->W, ctx->H, f->d_vis,
                            f->d_depth, tr, tw, LayerSink{});
     return WR_OK;
 }
@@ -637,7 +641,7 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
     {
         const RasterWS& ws = f->geom.ws;
         LayerSink ls{f->blend.rp_slot, f->d_vis, f->blend.bin_flag, f->blend.lists, f->blend.list_count, f->blend.cap};
-        hipLaunchKernelGGL((k_raster<kRasterLayers, 1024>), dim3((uint32_t)(ws.bins_x * ws.bins_y), 1, 1), dim3(1024), 0,
+        hipLaunchKernelGGL((k_raster<kRasterLayers, kColorRasterThreads>), dim3((uint32_t)(ws.bins_x * ws.bins_y), 1, 1), dim3(kColorRasterThreads), 0,
                            ms, ws, ctx->W, ctx->H, (uint32_t*)nullptr, (float*)nullptr, fc.tile_rank, fc.tile_world, ls);
         const size_t npx = (size_t)ctx->W * ctx->H;
         const uint32_t slot_groups = (uint32_t)std::min<size_t>((npx + 255) / 256, 2048);

@@ -410,18 +410,19 @@ __global__ __launch_bounds__(256) void k_bin_fill(RasterWS ws, int tile_rank, in
     }
 }
 
-// Exclusive prefix sum of the bin counts (one 1024-thread workgroup; n is a few thousand).
-__global__ __launch_bounds__(1024) void k_scan(RasterWS ws) {
-    __shared__ uint32_t part[1024];
+// Exclusive prefix sum of the bin counts (one workgroup; n is a few thousand to a few ten thousand).
+constexpr uint32_t kScanThreads = 256;  // small on purpose: has to find room next to long-running kernels of other frames
+__global__ __launch_bounds__(kScanThreads) void k_scan(RasterWS ws) {
+    __shared__ uint32_t part[kScanThreads];
     uint32_t n = (uint32_t)(ws.bins_x * ws.bins_y * ws.layers);
     uint32_t tid = threadIdx.x;
-    uint32_t chunk = (n + 1023u) / 1024u;
+    uint32_t chunk = (n + kScanThreads - 1u) / kScanThreads;
     uint32_t beg = min(tid * chunk, n), end = min(beg + chunk, n);
     uint32_t s = 0;
     for (uint32_t k = beg; k < end; ++k) s += ws.bin_count[k];
     part[tid] = s;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024u; d <<= 1) {
+    for (uint32_t d = 1; d < kScanThreads; d <<= 1) {
         uint32_t v = tid >= d ? part[tid - d] : 0u;
         __syncthreads();
         part[tid] += v;
@@ -432,9 +433,9 @@ __global__ __launch_bounds__(1024) void k_scan(RasterWS ws) {
         ws.bin_offset[k] = run;
         run += ws.bin_count[k];
     }
-    if (tid == 1023u) {
-        *ws.total_items = part[1023];
-        if (part[1023] > ws.items_cap) atomicOr(ws.err, kErrItemOverflow);
+    if (tid == kScanThreads - 1u) {
+        *ws.total_items = part[kScanThreads - 1u];
+        if (part[kScanThreads - 1u] > ws.items_cap) atomicOr(ws.err, kErrItemOverflow);
     }
 }
 
