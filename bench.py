@@ -42,7 +42,9 @@ import numpy as np  # noqa: E402
 # Algorithmic f32 operations of one executed fog_noise evaluation inside ray_march
 # (fog.wgsl:64-85 + 48-62, noise.wgsl): 2 fbm x 8 octaves x (8 hashes of 29-32 ops incl. a
 # 19-op software sine, smoothstep, 7 mixes) + the march bookkeeping; a fused multiply-add
-# counts as 2.  Derivation in DESIGN.md, "fog kernel".
+# counts as 2: sine 19; rand = dot 5 + sine 19 + 5 = 29 (+3 for the corner offset on 7 of 8
+# corners); value_noise = 6 + smoothstep 27 + hashes 29 + 7*32 + 7 mixes * 4 = 314; fbm =
+# 8 * (314 + 6) + 2 = 2562; fog_noise = 2 * 2562 + 58 + 4 = 5186; march bookkeeping 12.
 FLOP_PER_FOG_NOISE_EVAL = 5198
 PEAK_FP32_TFLOPS = 157.3   # MI355X f32 vector peak = dense f32 matrix peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
@@ -82,19 +84,21 @@ def algorithmic_bytes(sc, W, H, S, covered, fog_frags):
     return shadow + raster + shade + fog
 
 
-def cpu_baseline(sc, cam, light, glob, passes, W, H, S, threads):
-    """Times the CPU restatement (oracle/) on one full frame of the same workload."""
+def cpu_baseline(sc, cam, light, glob, passes, W, H, S, threads, frames=3):
+    """Times the CPU restatement (oracle/) on full frames of the same workload (median)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import Oracle
 
     o = Oracle(W, H, S)
     o.upload_scene(sc)
-    t0 = time.perf_counter()
-    o.render_frame(cam, light, glob, passes, threads=threads)
-    dt = time.perf_counter() - t0
+    times = []
+    for _ in range(frames):
+        t0 = time.perf_counter()
+        o.render_frame(cam, light, glob, passes, threads=threads)
+        times.append(time.perf_counter() - t0)
     cnt = o.counters()
     o.close()
-    return dt, cnt
+    return float(np.median(times)), cnt
 
 
 def main():
@@ -270,8 +274,8 @@ def main():
             cdt, ccnt = cpu_baseline(sc, cam, light, glob, passes, W, H, S, threads)
             cpu = {
                 "value": 1.0 / cdt, "unit": "frames/s", "cores": threads, "kind": "port",
-                "sample": f"1 full frame of the same workload ({W}x{H}, shadows+fog) on the CPU restatement in oracle/ "
-                          f"(reference wgpu-on-lavapipe path not buildable offline); {cdt:.2f} s",
+                "sample": f"median of 3 full frames of the same workload ({W}x{H}, shadows+fog) on the CPU restatement in oracle/ "
+                          f"(reference wgpu-on-lavapipe path not buildable offline); {cdt:.2f} s per frame",
                 "fog_noise_evals": int(ccnt["fog_noise_evals"]),
                 "fog_noise_evals_unused": int(ccnt["fog_noise_evals_unused"]),
             }
