@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--poses", type=int, default=512)
+    ap.add_argument("--animate", action="store_true",
+                    help="posebatch: t = time + k/60 for pose k (light, fog drift and shadow maps change every frame)")
     ap.add_argument("--frames-in-flight", type=int, default=4, choices=[1, 2, 3, 4],
                     help="sets of frame buffers the library alternates between (WrConfig.frames_in_flight)")
     args = ap.parse_args()
@@ -176,10 +178,13 @@ def main():
             return abi.camera_uniform(pos, pitch, yaw, rc["fovy"], W, H)
 
         poses = [pose_camera(k) for k in mine]
+        pose_light = [abi.light_at_time(args.time + k / 60.0) if args.animate else light for k in mine]
+        pose_glob = [abi.global_uniforms(args.time + k / 60.0, 1) if args.animate else glob for k in mine]
 
     def step(i):
         if args.workload == "posebatch":
-            r.render_frame(poses[i % len(poses)], light, glob, passes)
+            j = i % len(poses)
+            r.render_frame(poses[j], pose_light[j], pose_glob[j], passes)
         else:
             r.render_frame(cam, light, glob, passes)
             if gather_buf is not None:
@@ -295,7 +300,8 @@ def main():
             "config": {
                 "workload": {"frame": f"configs[2]: Sponza-class scene {W}x{H}, shadow map 6x{S}^2 + PCF, PBS, light marker, fog; "
                                       "reference default camera (-500,150,0) yaw 0, t=2.0; every pass recomputed each frame",
-                             "posebatch": f"configs[4]: {args.poses}-pose flythrough at {W}x{H}, shadows+fog, poses split contiguously over ranks",
+                             "posebatch": f"configs[4]: {args.poses}-pose flythrough at {W}x{H}, shadows+fog, poses split contiguously over ranks, "
+                                          + ("t = 2.0 + k/60 per pose" if args.animate else "t fixed") + ", every pass recomputed each frame",
                              "tiles4k": "configs[3]: 3840x2160 shadows+fog, 64x64 bins interleaved over ranks, RCCL all_gather of colour bins"}[args.workload],
                 "scene": scene_name,
                 "triangles": sc.geometry.triangle_count,
