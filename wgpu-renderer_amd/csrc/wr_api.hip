@@ -35,8 +35,8 @@ static_assert(sizeof(WrMaterialUniform) == 16, "MaterialUniform layout (material
 #define WR_COLOR_RASTER_THREADS 256
 #endif
 constexpr int kColorRasterThreads = WR_COLOR_RASTER_THREADS;
-constexpr size_t kNoiseLevelEntries = 2u << 20;  // largest hash table of one noise level
-constexpr size_t kNoisePoolEntries = 4u << 20;   // all levels together (16 MB)
+constexpr size_t kNoiseLevelEntries = 16u << 20;  // largest hash table of one noise level
+constexpr size_t kNoisePoolEntries = 32u << 20;   // all levels together (128 MB per frame in flight)
 static_assert(sizeof(FrameConsts) < 3072, "FrameConsts must fit the kernel argument segment");
 
 namespace {
@@ -602,8 +602,15 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
         hipLaunchKernelGGL(k_setup_small, grid1(fm.ntris), dim3(256), 0, ss, fm.pos, fm.idx, fm.ntris, 1, 1, 0u, f->fog.ws, fc);
         uint32_t max_entries = 0;
         fa.tables_noise = plan_noise_tables(ctx, f, fc, &max_entries);
-        if (max_entries)
-            hipLaunchKernelGGL(k_fog_tables, dim3((max_entries + 255u) / 256u, 16, 1), dim3(256), 0, ss, fa.tables_noise);
+        if (max_entries) {
+            TablePlan plan{};
+            for (int l = 0; l < 16; ++l) {
+                const NoiseTable& t = fa.tables_noise.level[l];
+                plan.chunks[l] = t.data ? ((uint32_t)t.nx + 255u) / 256u : 1u;
+                plan.wg_begin[l + 1] = plan.wg_begin[l] + (t.data ? plan.chunks[l] * (uint32_t)t.ny * (uint32_t)t.nz : 0u);
+            }
+            hipLaunchKernelGGL(k_fog_tables, dim3(plan.wg_begin[16]), dim3(256), 0, ss, fa.tables_noise, plan);
+        }
         fa.fc = fc; fa.ws = f->fog.ws; fa.pos = fm.pos; fa.idx = fm.idx; fa.ntris = fm.ntris;
         fa.depth = f->d_depth; fa.color = f->d_color; fa.shadow = f->d_shadow; fa.tables = ctx->d_tables;
         fa.counters = ctx->d_counters;

@@ -1212,14 +1212,25 @@ __global__ __launch_bounds__(64) void k_fog_multi(FogArgs a) {
     }
 }
 
-// Fills the hash table of one noise level: entry (i,j,k) = hash of lattice point lo + (i,j,k).
-__global__ __launch_bounds__(256) void k_fog_tables(NoiseTables nt) {
-    const NoiseTable t = nt.level[blockIdx.y];
-    if (t.data == nullptr) return;
-    const size_t n = (size_t)t.nx * t.ny * t.nz;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    int ix = (int)(i % (size_t)t.nx), iy = (int)((i / (size_t)t.nx) % (size_t)t.ny), iz = (int)(i / ((size_t)t.nx * t.ny));
+// Fills the hash tables: entry (i,j,k) of a level = hash of lattice point lo + (i,j,k).  The
+// workgroups of all levels form one grid; a workgroup takes up to 256 consecutive x of one
+// (y, z) row of its level, so a thread decodes no index.
+struct TablePlan {
+    uint32_t wg_begin[17];  // first workgroup of each level (level l owns [wg_begin[l], wg_begin[l+1]))
+    uint32_t chunks[16];    // workgroups per row = ceil(nx / 256)
+};
+__global__ __launch_bounds__(256) void k_fog_tables(NoiseTables nt, TablePlan plan) {
+    const uint32_t b = blockIdx.x;
+    int level = 0;
+    while (level < 15 && b >= plan.wg_begin[level + 1]) ++level;
+    const NoiseTable t = nt.level[level];
+    if (t.data == nullptr || b >= plan.wg_begin[level + 1]) return;
+    const uint32_t local = b - plan.wg_begin[level];
+    const uint32_t row = local / plan.chunks[level], chunk = local % plan.chunks[level];
+    const int iy = (int)(row % (uint32_t)t.ny), iz = (int)(row / (uint32_t)t.ny);
+    const int ix = (int)(chunk * 256u + threadIdx.x);
+    if (ix >= t.nx) return;
+    const size_t i = ((size_t)iz * t.ny + iy) * t.nx + ix;
     const_cast<float*>(t.data)[i] = lattice_hash((float)(t.lox + ix), (float)(t.loy + iy), (float)(t.loz + iz));
 }
 
