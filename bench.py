@@ -51,9 +51,9 @@ PEAK_HBM_GBS = 8000.0
 # HBM bytes of one k_fog_march launch on the default frame, from the rocprofv3 PMC passes kept
 # in profiles/ (FETCH_SIZE doubled as the gfx950 note prescribes, plus WRITE_SIZE); None until
 # such a pass has been recorded for the current kernel.  (Algorithmic bytes of a launch: 20 B
-# read + 16 B written per work item = 24 MB; the rest is the 9 MB of noise tables and the shadow
-# map taps, re-fetched by the eight L2s.)
-FOG_MARCH_HBM_BYTES = (2 * 22460 + 10420) * 1024  # profiles/r01_v3_pmc_hbm.txt
+# read + 16 B written per work item = 24 MB; the rest is the 86 MB of noise tables and the shadow
+# map taps.)
+FOG_MARCH_HBM_BYTES = (2 * 50150 + 10420) * 1024  # profiles/r01_v4_pmc_hbm.txt
 
 
 def build_scene(args):
@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--poses", type=int, default=512)
+    ap.add_argument("--skip-march-alone", action="store_true",
+                    help="leave out the extra one-frame-in-flight pass after the timed region (for profiling runs)")
     ap.add_argument("--animate", action="store_true",
                     help="posebatch: t = time + k/60 for pose k (light, fog drift and shadow maps change every frame)")
     ap.add_argument("--frames-in-flight", type=int, default=4, choices=[1, 2, 3, 4],
@@ -224,7 +226,7 @@ def main():
     # shading kernels), outside the timed region: how fast the march runs when it does not
     # share the device with the marches of the neighbouring frames.
     march_alone_ms = None
-    if rank == 0 and args.workload == "frame" and in_flight > 1:
+    if rank == 0 and args.workload == "frame" and in_flight > 1 and not args.skip_march_alone:
         r1 = abi.Renderer(W, H, S, device=local_rank, frames_in_flight=1)
         r1.upload_scene(sc)
         for i in range(3):
