@@ -485,3 +485,59 @@ def test_full_size_properties(full_scene):
         rr.close()
     assert np.array_equal(gathered.read_color(), ref)
     gathered.close()
+
+
+def test_4k_bin_sharding_over_eight_contexts(full_scene):
+    """BASELINE configs[3]: 3840x2160 with the 64x64 bins interleaved over eight ranks; the
+    gathered frame equals the frame one context renders alone."""
+    import torch
+    w, h, s = 3840, 2160, 2048
+    cam, light, glob = default_inputs(w, h)
+    whole = abi.Renderer(w, h, s)
+    whole.upload_scene(full_scene)
+    whole.render_frame(cam, light, glob, abi.PASS_ALL)
+    ref = whole.read_color()
+    ref_depth = whole.read_depth()
+    assert (ref[..., :3].max(axis=2) > 0).mean() > 0.5  # a real frame, not the clear colour
+    world = 8
+    nb = ((w + 63) // 64) * ((h + 63) // 64)
+    per = (nb + world - 1) // world
+    for rank in range(world):
+        rr = abi.Renderer(w, h, s, tile_rank=rank, tile_world=world)
+        rr.upload_scene(full_scene)
+        rr.render_frame(cam, light, glob, abi.PASS_ALL)
+        packed = torch.zeros(per * 64 * 64, dtype=torch.int32, device="cuda")
+        n = rr.pack_owned_bins(packed.data_ptr())
+        rr.sync()
+        assert n == len(range(rank, nb, world))
+        d = rr.read_depth()
+        rr.close()
+        # the rank's own bins carry the same depth as the whole frame
+        by, bx = np.divmod(np.arange(rank, nb, world), (w + 63) // 64)
+        for k in (0, len(by) // 2, len(by) - 1):
+            ys, xs = slice(by[k] * 64, min(by[k] * 64 + 64, h)), slice(bx[k] * 64, min(bx[k] * 64 + 64, w))
+            assert np.array_equal(d[ys, xs], ref_depth[ys, xs])
+        whole.scatter_bins(packed.data_ptr(), rank, world)  # overwrite the whole frame bin by bin
+        whole.sync()
+    assert np.array_equal(whole.read_color(), ref)
+    whole.close()
+
+
+def test_largest_target(tiny_scene):
+    """7168 x 7168 is the largest target wr_create accepts (16-bit pixel coordinates in the
+    set-up records, guard band of 8w); one more pixel is an argument error."""
+    w = h = 7168
+    cam, light, glob = default_inputs(w, h)
+    r = abi.Renderer(w, h, 64)
+    r.upload_scene(tiny_scene)
+    r.render_frame(cam, light, glob, abi.PASS_ALL)
+    vis = r.read_visibility()
+    col = r.read_color()
+    r.close()
+    assert vis.shape == (h, w) and (vis != 0xFFFFFFFF).mean() > 0.3
+    # the same view at 1/8 size covers the same share of the target
+    small = render_gpu(tiny_scene, *default_inputs(896, 896), abi.PASS_ALL, 896, 896, 64)
+    assert abs((vis != 0xFFFFFFFF).mean() - (small["vis"] != 0xFFFFFFFF).mean()) < 0.01
+    assert col.shape == (h, w, 4) and (col[..., :3].max(axis=2) > 0).mean() > 0.3
+    with pytest.raises(abi.WrError):
+        abi.Renderer(7169, 64, 64)
