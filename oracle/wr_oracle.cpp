@@ -527,6 +527,22 @@ inline float shadow_compare(const Frame& F, float u, float v, int layer, float r
     return lerpf(lerpf(c00, c10, fx), lerpf(c01, c11, fx), fy);
 }
 
+// constants.wgsl:1-17 under the shaders' own names (PI is PI_C here: <cmath> may define PI-like
+// macros).  INV_SHADOW_SAMPLES is 1/25 although the loops take 16 taps, as in the reference.
+const float PI_C = 3.14159f;
+const float INV_SQRT_2 = 0.70710678118654752440f;
+const float INV_SQRT_3 = 0.57735026918962576451f;
+const int SHADOW_SAMPLES = 2;
+const float INV_SHADOW_SAMPLES = 1.0f / 25.0f;
+const int FOG_MAX_STEPS = 30;
+const float FOG_STEP_SIZE = 5.0f;
+const int FOG_LIGHT_MAX_STEPS = 10;
+const float FOG_LIGHT_STEP_SIZE = 10.0f;
+const float FOG_DENSITY = 2.0f;
+const float FOG_LIGHT_DENSITY = 3.0f;
+const float FOG_ALPHA = 1.0f;
+const float FOG_DENSITY_COLOR[2] = {0.5f, 0.1f};
+
 // light.wgsl:1-29
 float sample_direct_light_index(const Frame& F, int index, V4 lc) {
     if (lc.w <= 0.0f) return 0.0f;
@@ -536,11 +552,11 @@ float sample_direct_light_index(const Frame& F, int index, V4 lc) {
     float ref = lc.z * proj_correction - 0.000001f;
     float total = 0.0f;
     float texel_size = (float)F.S;
-    for (int x = -2; x < 2; ++x)
-        for (int y = -2; y < 2; ++y) {
+    for (int x = -SHADOW_SAMPLES; x < SHADOW_SAMPLES; ++x)
+        for (int y = -SHADOW_SAMPLES; y < SHADOW_SAMPLES; ++y) {
             float ox = (float)x / texel_size, oy = (float)y / texel_size;
             float s = shadow_compare(F, lx + ox, ly + oy, index, ref);
-            total += s * (1.0f / 25.0f);
+            total += s * INV_SHADOW_SAMPLES;
         }
     return total;
 }
@@ -552,9 +568,9 @@ float sample_direct_light(const Frame& F, V4 wp) {
         for (int i = 0; i < 6; ++i) {
             V4 lc = mul(F.light_m[i], wp);
             V3 ld = normalize3(v3(lc.x, lc.y, lc.z));
-            if (ld.z < 0.57735026918962576451f - 0.01f) continue;
-            if (fabsf(ld.y) > 0.70710678118654752440f + 0.01f) continue;
-            if (fabsf(ld.x) > 0.70710678118654752440f + 0.01f) continue;
+            if (ld.z < INV_SQRT_3 - 0.01f) continue;
+            if (fabsf(ld.y) > INV_SQRT_2 + 0.01f) continue;
+            if (fabsf(ld.x) > INV_SQRT_2 + 0.01f) continue;
             in_light = sample_direct_light_index(F, i, lc);
             if (in_light > 0.0f) break;
         }
@@ -572,8 +588,6 @@ V3 sample_ambient_light(V4 light, float light_dist, float surface_light_dot) {
     float diffuse_mult = fmaxf(surface_light_dot, 0.0f);
     return ambient + diff_direct * (diffuse_mult * 0.03f);
 }
-
-const float PI_C = 3.14159f;  // constants.wgsl:1
 
 // brdf.wgsl:35-65
 V3 brdf(V3 n, V3 l, V3 v, V3 h, V3 albedo, float roughness, float metalness) {
@@ -682,19 +696,19 @@ V4 fs_fog(const Scene& sc, const float* depth_tex, V3 origin, float frag_z, int 
     float max_fog_depth = geometry_depth - volume_depth;
     if (max_fog_depth <= 0.0f) return V4{0, 0, 0, 0};
     // ray_march_fog
-    V2 fm = ray_march(F, origin, direction, max_fog_depth, 30, 5.0f, 2.0f, cnt);
+    V2 fm = ray_march(F, origin, direction, max_fog_depth, FOG_MAX_STEPS, FOG_STEP_SIZE, FOG_DENSITY, cnt);
     float fog_density = fm.x, fog_depth = fm.y;
     V3 fog_end = origin + direction * fog_depth;
     V3 to_light = F.light_pos - fog_end;
     float max_light_dist = length3(to_light);
     V3 light_direction = to_light / max_light_dist;
     const uint64_t evals_before_light_march = cnt.fog_noise_evals;
-    V2 lm = ray_march(F, fog_end, light_direction, max_light_dist, 10, 10.0f, 3.0f, cnt);
+    V2 lm = ray_march(F, fog_end, light_direction, max_light_dist, FOG_LIGHT_MAX_STEPS, FOG_LIGHT_STEP_SIZE, FOG_LIGHT_DENSITY, cnt);
     const uint64_t light_march_evals = cnt.fog_noise_evals - evals_before_light_march;
     float occlusion = lm.x;
     V3 fog_position = origin + direction * fog_depth;
     float light_dist = length3(F.light_pos - fog_position);
-    float bc = mixf(0.5f, 0.1f, fog_density);
+    float bc = mixf(FOG_DENSITY_COLOR[0], FOG_DENSITY_COLOR[1], fog_density);
     V3 ambient = sample_ambient_light(F.light_color, light_dist, 1.0f) * 2.0f;
     ambient = ambient * v3(bc, bc, bc);
     V3 radiance = v3(0, 0, 0);
@@ -708,7 +722,7 @@ V4 fs_fog(const Scene& sc, const float* depth_tex, V3 origin, float frag_z, int 
     }
     V3 result = ambient + radiance;
     result = result / (result + v3(1, 1, 1));
-    return V4{result.x, result.y, result.z, fog_density * 1.0f};
+    return V4{result.x, result.y, result.z, fog_density * FOG_ALPHA};
 }
 
 // R15

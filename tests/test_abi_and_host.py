@@ -360,3 +360,55 @@ def test_native_glb_importer_on_the_reference_cube():
     for i, (px, srgb) in enumerate(textures):
         a, s = g.texture(i)
         assert np.array_equal(a, px) and s == srgb
+
+
+def _numeric_constants(text, decl):
+    """name -> list of floats for every `<decl> NAME[...] = expr;` whose expr is numbers, '/', ',' only."""
+    import re
+    out = {}
+    for m in re.finditer(decl + r"\s+(\w+)(?:\[\d+\])?\s*=\s*([^;]+);", text):
+        expr = re.sub(r"vec2<f32>|[{}()]", " ", m.group(2))
+        expr = re.sub(r"(?<=[0-9.])f\b", "", expr)
+        if not re.fullmatch(r"[\d\s.,/+-]+", expr):
+            continue
+        vals = []
+        for part in expr.split(","):
+            if part.strip():
+                num = [float(x) for x in part.split("/")]
+                v = num[0]
+                for d in num[1:]:
+                    v /= d
+                vals.append(v)
+        out[m.group(1)] = vals
+    return out
+
+
+def test_shader_constants_equal_the_reference_shaders():
+    """Every constant of the reference's constants.wgsl is present, under a recognisable name
+    and with the same value, in the device arithmetic and in the oracle."""
+    ref = "/root/reference/res/shaders/constants.wgsl"
+    if not os.path.exists(ref):
+        pytest.skip("reference checkout not present")
+    wgsl = _numeric_constants(open(ref).read(), r"const")
+    assert len(wgsl) >= 13 and wgsl["FOG_MAX_STEPS"] == [30.0]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dev = {}
+    for decl in (r"constexpr float", r"constexpr int"):
+        dev.update(_numeric_constants(open(os.path.join(root, "wgpu-renderer_amd", "csrc", "wr_device.h")).read(), decl))
+    # `constexpr float kA = 0.5f, kB = 0.1f;` declares two names in one statement
+    dev_text = open(os.path.join(root, "wgpu-renderer_amd", "csrc", "wr_device.h")).read()
+    import re
+    m = re.search(r"kFogDensityColorX = ([\d.]+)f, kFogDensityColorY = ([\d.]+)f;", dev_text)
+    dev["kFogDensityColor"] = [float(m.group(1)), float(m.group(2))]
+    orc = {}
+    for decl in (r"const float", r"const int"):
+        orc.update(_numeric_constants(open(os.path.join(root, "oracle", "wr_oracle.cpp")).read(), decl))
+
+    def camel(name):
+        return "k" + "".join(p.capitalize() if not p.isdigit() else p for p in name.lower().split("_"))
+
+    for name, val in wgsl.items():
+        f32 = [float(np.float32(x)) for x in val]
+        oname = "PI_C" if name == "PI" else name
+        assert [float(np.float32(x)) for x in orc[oname]] == f32, name
+        assert [float(np.float32(x)) for x in dev[camel(name)]] == f32, name

@@ -445,6 +445,8 @@ bool fog_sample_bounds(const WrContext* ctx, const FrameConsts& fc, double lo[3]
     double centre[3] = {0, 0, 0};
     for (int c = 0; c < 8; ++c) for (int r = 0; r < 3; ++r) centre[r] += corner[c][r] / 8.0;
     for (int r = 0; r < 3; ++r) { lo[r] = 1e300; hi[r] = -1e300; }
+    const double view_reach = (double)kFogMaxSteps * kFogStepSize;
+    const double light_reach = (double)kFogLightMaxSteps * kFogLightStepSize;
     bool any = false;
     for (int fi = 0; fi < 6; ++fi) {
         // faces turned away from the camera produce no fragments (back-face culling); which way
@@ -495,7 +497,7 @@ bool fog_sample_bounds(const WrContext* ctx, const FrameConsts& fc, double lo[3]
             for (int r = 0; r < 3; ++r) { d[r] = q.w[r] - (double)fc.cam_pos[r]; len += d[r] * d[r]; }
             len = std::sqrt(len);
             for (int r = 0; r < 3; ++r) {
-                const double e = len > 0.0 ? q.w[r] + 150.0 * d[r] / len : q.w[r];
+                const double e = len > 0.0 ? q.w[r] + view_reach * d[r] / len : q.w[r];
                 lo[r] = std::min(lo[r], std::min(q.w[r], e));
                 hi[r] = std::max(hi[r], std::max(q.w[r], e));
             }
@@ -505,8 +507,8 @@ bool fog_sample_bounds(const WrContext* ctx, const FrameConsts& fc, double lo[3]
     if (!any) return false;
     for (int r = 0; r < 3; ++r) {
         const double L = fc.light_pos[r];
-        lo[r] = std::min(lo[r], std::max(L, lo[r] - 100.0)) - 3.0;
-        hi[r] = std::max(hi[r], std::min(L, hi[r] + 100.0)) + 3.0;
+        lo[r] = std::min(lo[r], std::max(L, lo[r] - light_reach)) - 3.0;
+        hi[r] = std::max(hi[r], std::min(L, hi[r] + light_reach)) + 3.0;
     }
     return true;
 }

@@ -452,6 +452,22 @@ WR_HD float shadow_compare(const ShadowMap& sm, float u, float v, int layer, flo
     return lerpf(lerpf(c00, c10, fx), lerpf(c01, c11, fx), fy);
 }
 
+// constants.wgsl:1-17, value for value (PI is the reference's truncated 3.14159 on purpose;
+// INV_SHADOW_SAMPLES is 1/25 although the loops below take 16 taps).
+constexpr float kPi = 3.14159f;
+constexpr float kInvSqrt2 = 0.70710678118654752440f;
+constexpr float kInvSqrt3 = 0.57735026918962576451f;
+constexpr int kShadowSamples = 2;
+constexpr float kInvShadowSamples = 1.0f / 25.0f;
+constexpr int kFogMaxSteps = 30;
+constexpr float kFogStepSize = 5.0f;
+constexpr int kFogLightMaxSteps = 10;
+constexpr float kFogLightStepSize = 10.0f;
+constexpr float kFogDensity = 2.0f;
+constexpr float kFogLightDensity = 3.0f;
+constexpr float kFogAlpha = 1.0f;
+constexpr float kFogDensityColorX = 0.5f, kFogDensityColorY = 0.1f;
+
 // light.wgsl:1-29.  The loops run x,y in [-2,2): 16 taps weighted 1/25 each.
 WR_HD float sample_direct_light_index(const ShadowMap& sm, int index, V4 lc) {
     if (lc.w <= 0.0f) return 0.0f;
@@ -461,11 +477,11 @@ WR_HD float sample_direct_light_index(const ShadowMap& sm, int index, V4 lc) {
     float ref = lc.z * pc - 0.000001f;
     float total = 0.0f;
     float ts = (float)sm.S;
-    for (int x = -2; x < 2; ++x)
-        for (int y = -2; y < 2; ++y) {
+    for (int x = -kShadowSamples; x < kShadowSamples; ++x)
+        for (int y = -kShadowSamples; y < kShadowSamples; ++y) {
             float ox = (float)x / ts, oy = (float)y / ts;
             float s = shadow_compare(sm, lx + ox, ly + oy, index, ref);
-            total += s * (1.0f / 25.0f);
+            total += s * kInvShadowSamples;
         }
     return total;
 }
@@ -477,9 +493,9 @@ WR_HD float sample_direct_light(const FrameConsts& fc, const ShadowMap& sm, V4 w
         for (int i = 0; i < 6; ++i) {
             V4 lc = mat4_mul(fc.light_m[i], wp);
             V3 ld = normalize3(v3(lc.x, lc.y, lc.z));
-            if (ld.z < 0.57735026918962576451f - 0.01f) continue;
-            if (fabsf(ld.y) > 0.70710678118654752440f + 0.01f) continue;
-            if (fabsf(ld.x) > 0.70710678118654752440f + 0.01f) continue;
+            if (ld.z < kInvSqrt3 - 0.01f) continue;
+            if (fabsf(ld.y) > kInvSqrt2 + 0.01f) continue;
+            if (fabsf(ld.x) > kInvSqrt2 + 0.01f) continue;
             in_light = sample_direct_light_index(sm, i, lc);
             if (in_light > 0.0f) break;
         }
@@ -496,8 +512,6 @@ WR_HD V3 sample_ambient_light(const float* light, float light_dist, float surfac
     float diffuse_mult = fmaxf(surface_light_dot, 0.0f);
     return v3(0.01f, 0.01f, 0.01f) + diff_direct * (diffuse_mult * 0.03f);
 }
-
-constexpr float kPi = 3.14159f;  // constants.wgsl:1 (truncated on purpose)
 
 // brdf.wgsl:35-65 with its helpers 3-33.  pow(x, 5.0) is evaluated as (x*x)*(x*x)*x.
 WR_HD V3 brdf(V3 n, V3 l, V3 v, V3 h, V3 albedo, float roughness, float metalness) {
@@ -728,12 +742,12 @@ WR_HD V4 fog_march_shade(const FrameConsts& fc, const ShadowMap& sm, const Noise
     V3 cam = v3(fc.cam_pos[0], fc.cam_pos[1], fc.cam_pos[2]);
     V3 lp = v3(fc.light_pos[0], fc.light_pos[1], fc.light_pos[2]);
     V3 direction = normalize3(origin - cam);
-    V2 fm = ray_march(fc, nt, origin, direction, max_fog_depth, 30, 5.0f, 2.0f, evals);
+    V2 fm = ray_march(fc, nt, origin, direction, max_fog_depth, kFogMaxSteps, kFogStepSize, kFogDensity, evals);
     float fog_density = fm.x, fog_depth = fm.y;
     V3 fog_end = origin + direction * fog_depth;
     V3 fog_position = origin + direction * fog_depth;
     float light_dist = length3(lp - fog_position);
-    float bc = mixf(0.5f, 0.1f, fog_density);
+    float bc = mixf(kFogDensityColorX, kFogDensityColorY, fog_density);
     V3 ambient = sample_ambient_light(fc.light_color, light_dist, 1.0f) * 2.0f;
     ambient = ambient * v3(bc, bc, bc);
     V3 radiance = v3(0.0f, 0.0f, 0.0f);
@@ -744,14 +758,14 @@ WR_HD V4 fog_march_shade(const FrameConsts& fc, const ShadowMap& sm, const Noise
         V3 to_light = lp - fog_end;
         float max_light_dist = length3(to_light);
         V3 light_direction = to_light / max_light_dist;
-        V2 lm = ray_march(fc, nt, fog_end, light_direction, max_light_dist, 10, 10.0f, 3.0f, evals);
+        V2 lm = ray_march(fc, nt, fog_end, light_direction, max_light_dist, kFogLightMaxSteps, kFogLightStepSize, kFogLightDensity, evals);
         float occlusion = lm.x;
         float att = 1.0f / (1.0f + light_dist * light_dist);
         radiance = (((v3(fc.light_color[0], fc.light_color[1], fc.light_color[2]) * fc.light_color[3]) * att) * in_light) * (1.0f - occlusion);
     }
     V3 result = ambient + radiance;
     result = result / (result + v3(1.0f, 1.0f, 1.0f));
-    return V4{result.x, result.y, result.z, fog_density * 1.0f};
+    return V4{result.x, result.y, result.z, fog_density * kFogAlpha};
 }
 
 }  // namespace wr
