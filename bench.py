@@ -40,12 +40,13 @@ if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 16:
 import numpy as np  # noqa: E402
 
 # Algorithmic f32 operations of one executed fog_noise evaluation inside ray_march
-# (fog.wgsl:64-85 + 48-62, noise.wgsl): 2 fbm x 8 octaves x (8 hashes of 29-32 ops incl. a
-# 19-op software sine, smoothstep, 7 mixes) + the march bookkeeping; a fused multiply-add
-# counts as 2: sine 19; rand = dot 5 + sine 19 + 5 = 29 (+3 for the corner offset on 7 of 8
-# corners); value_noise = 6 + smoothstep 27 + hashes 29 + 7*32 + 7 mixes * 4 = 314; fbm =
-# 8 * (314 + 6) + 2 = 2562; fog_noise = 2 * 2562 + 58 + 4 = 5186; march bookkeeping 12.
-FLOP_PER_FOG_NOISE_EVAL = 5198
+# (fog.wgsl:64-85 + 48-62, noise.wgsl): 2 fbm x 8 octaves x (8 hashes of 31-34 ops incl. a
+# 21-op software sine, smoothstep, 7 mixes) + the march bookkeeping; a fused multiply-add
+# counts as 2: sine = quotient 3 + reduction 6 + z 1 + polynomial 8 + r*z 1 + last step 2 = 21;
+# rand = dot 5 + sine 21 + 5 = 31 (+3 for the corner offset on 7 of 8 corners); value_noise =
+# 6 + smoothstep 27 + hashes 31 + 7*34 + 7 mixes * 4 = 330; fbm = 8 * (330 + 6) + 2 = 2690;
+# fog_noise = 2 * 2690 + 58 + 4 = 5442; march bookkeeping 12.
+FLOP_PER_FOG_NOISE_EVAL = 5454
 PEAK_FP32_TFLOPS = 157.3   # MI355X f32 vector peak = dense f32 matrix peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 # HBM bytes of one k_fog_march launch on the default frame, from the rocprofv3 PMC passes kept

@@ -3,10 +3,77 @@
 // Test infrastructure: exposes single functions only, no rendering path.
 #include <cstring>
 #include <cmath>
+#include <hip/hip_runtime.h>
 #include "../../wgpu-renderer_amd/csrc/wr_device.h"
 using namespace wr;
 
+// Device-side unit checks (GPU tests only): the same functions evaluated by a kernel.
+__global__ void k_hc_hash(const float* d, int n, float* out_guarded, float* out_unguarded) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out_guarded[i] = hash_from_dot<true>(d[i]);
+    out_unguarded[i] = hash_from_dot<false>(d[i]);
+}
+__global__ void k_hc_sin(const float* x, int n, float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = wr_sin(x[i]);
+}
+// Over every f32 bit pattern: how often the hardware fraction differs from s - floor(s) where
+// the latter is a number below 1 (where it rounds up to 1 the hardware returns the float below).
+__global__ void k_hc_fract(unsigned long long* mismatches) {
+    unsigned long long bad = 0;
+    for (unsigned long long b = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b < (1ull << 32);
+         b += (unsigned long long)gridDim.x * blockDim.x) {
+        float s = u2f((uint32_t)b);
+        float want = s - floorf(s);
+        if (!(want < 1.0f)) continue;  // also NaN and infinities
+        if (f2u(__builtin_amdgcn_fractf(s)) != f2u(want)) ++bad;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 extern "C" {
+// returns 0, or the HIP error code
+int hc_dev_hash(const float* d, int n, float* out_guarded, float* out_unguarded) {
+    float *dd = nullptr, *dg = nullptr, *du = nullptr;
+    hipError_t e = hipMalloc(&dd, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc(&dg, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc(&du, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMemcpy(dd, d, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        k_hc_hash<<<(n + 255) / 256, 256>>>(dd, n, dg, du);
+        e = hipDeviceSynchronize();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out_guarded, dg, (size_t)n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_unguarded, du, (size_t)n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(dd); (void)hipFree(dg); (void)hipFree(du);
+    return (int)e;
+}
+int hc_dev_sin(const float* x, int n, float* out) {
+    float *dx = nullptr, *dout = nullptr;
+    hipError_t e = hipMalloc(&dx, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc(&dout, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMemcpy(dx, x, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        k_hc_sin<<<(n + 255) / 256, 256>>>(dx, n, dout);
+        e = hipDeviceSynchronize();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(dx); (void)hipFree(dout);
+    return (int)e;
+}
+long long hc_dev_fract_mismatches() {
+    unsigned long long* dm = nullptr;
+    unsigned long long m = 0;
+    if (hipMalloc(&dm, 8) != hipSuccess) return -1;
+    if (hipMemset(dm, 0, 8) != hipSuccess) return -1;
+    k_hc_fract<<<4096, 256>>>(dm);
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpy(&m, dm, 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    (void)hipFree(dm);
+    return (long long)m;
+}
+float hc_hash_from_dot(float d) { return hash_from_dot<true>(d); }
 float hc_sin(float x) { return wr_sin(x); }
 float hc_value_noise(const float* p) { return value_noise(v3(p[0], p[1], p[2])); }
 float hc_fbm(const float* p) { return fbm(v3(p[0], p[1], p[2])); }

@@ -541,3 +541,71 @@ def test_largest_target(tiny_scene):
     assert col.shape == (h, w, 4) and (col[..., :3].max(axis=2) > 0).mean() > 0.3
     with pytest.raises(abi.WrError):
         abi.Renderer(7169, 64, 64)
+
+
+# ------------------------------------------------------------------ device arithmetic units
+def _hostcheck():
+    import ctypes as C
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostcheck", "libwr_hostcheck.so")
+    H = C.CDLL(path)
+    fp = C.POINTER(C.c_float)
+    H.hc_dev_sin.argtypes = [fp, C.c_int, fp]
+    H.hc_dev_hash.argtypes = [fp, C.c_int, fp, fp]
+    H.hc_dev_fract_mismatches.restype = C.c_longlong
+    return H, fp
+
+
+def _hash_arguments():
+    """Arguments the noise hash sees: dot products of integer lattice points (noise.wgsl:4), a
+    dense sweep, values around multiples of pi, the range limit, zeros, NaN and infinities.  No
+    non-zero value below 2^-20 in magnitude: a lattice dot product cannot be one."""
+    rng = np.random.default_rng(11)
+    f32 = np.float32
+    u = np.floor(rng.uniform(-17000, 17000, (400000, 3))).astype(f32)
+    u[:50000] = np.floor(rng.uniform(-40, 40, (50000, 3))).astype(f32)
+    dots = (u[:, 0] * f32(12.345) + u[:, 1] * f32(67.89)) + u[:, 2] * f32(412.12)
+    k = np.arange(1, 200001, dtype=np.float64) * np.pi
+    near_pi = np.concatenate([k.astype(f32), np.nextafter(k.astype(f32), f32(np.inf)), -k.astype(f32)])
+    special = np.array([0.0, -0.0, 2.0 ** -20, -(2.0 ** -20), 8388607.5, 8388608.0, -8388608.0, 8388609.0, 1e9, -3e38,
+                        np.inf, -np.inf, np.nan], dtype=f32)
+    sweep = rng.uniform(-8.4e6, 8.4e6, 300000).astype(f32)
+    small = rng.uniform(-20, 20, 100000).astype(f32)
+    return np.ascontiguousarray(np.concatenate([dots, near_pi, special, sweep, small]).astype(f32))
+
+
+def test_device_sine_and_hash_equal_the_oracle_bit_for_bit():
+    import ctypes as C
+    from oracle_lib import lib as oracle_lib_handle
+    H, fp = _hostcheck()
+    L = oracle_lib_handle()
+    x = _hash_arguments()
+    n = len(x)
+    s_dev = np.empty(n, np.float32)
+    hg = np.empty(n, np.float32)
+    hu = np.empty(n, np.float32)
+    assert H.hc_dev_sin(x.ctypes.data_as(fp), n, s_dev.ctypes.data_as(fp)) == 0
+    assert H.hc_dev_hash(x.ctypes.data_as(fp), n, hg.ctypes.data_as(fp), hu.ctypes.data_as(fp)) == 0
+    L.wro_sin_many.argtypes = [fp, C.c_int, fp]
+    L.wro_hash_many.argtypes = [fp, C.c_int, fp]
+    s_or = np.empty(n, np.float32)
+    h_or = np.empty(n, np.float32)
+    L.wro_sin_many(x.ctypes.data_as(fp), n, s_or.ctypes.data_as(fp))
+    L.wro_hash_many(x.ctypes.data_as(fp), n, h_or.ctypes.data_as(fp))
+    assert np.array_equal(s_dev.view(np.uint32), s_or.view(np.uint32))
+    assert np.array_equal(hg.view(np.uint32), h_or.view(np.uint32))
+    # the unguarded form is only ever called below the range limit, where it must agree
+    inr = np.abs(x) < np.float32(8388608.0)
+    assert np.array_equal(hu.view(np.uint32)[inr], h_or.view(np.uint32)[inr])
+    # accuracy of the shared sine against double precision over the whole range it serves
+    ok = inr & np.isfinite(x)
+    assert np.abs(s_dev[ok].astype(np.float64) - np.sin(x[ok].astype(np.float64))).max() < 1.5e-7
+    assert np.all((h_or[np.isfinite(h_or)] >= -1.0) & (h_or[np.isfinite(h_or)] <= 1.0))
+
+
+def test_device_fraction_instruction_equals_x_minus_floor():
+    """The hash takes its fractional part with the hardware's fraction instruction; over all
+    2^32 f32 values it equals x - floor(x) wherever that is below 1 (the hash never sees the
+    other case: checked exhaustively on the CPU for every argument of at least 2^-20 in
+    magnitude, the smallest non-zero lattice dot product)."""
+    H, _ = _hostcheck()
+    assert H.hc_dev_fract_mismatches() == 0

@@ -76,45 +76,41 @@ inline void mat4_mul_mat4(const float* a, const float* b, float* out) {  // out 
     }
 }
 
-// Software sine used by the fog noise hash (noise.wgsl:4).  Single-precision Cephes
-// scheme: octant j from x*4/pi, three-constant reduction, one of two cubic-in-z
-// polynomials; the reduction and Horner steps are fused multiply-adds.  |x| >= 2^30 -> 0.
-// GUARD = false is for callers that have already bounded |x| below 2^30; for such x both
-// forms return the same bits.
+// Software sine used by the fog noise hash (noise.wgsl:4): WGSL leaves the accuracy of sin
+// to the implementation, so the restatement fixes one algorithm and both sides run it.
+//   q  = x/pi rounded to the nearest integer by adding 1.5*2^23 in a fused multiply-add
+//        (exact rounding for |q| < 2^22; the sum's lowest mantissa bit is q's parity),
+//   r  = x - q*pi, pi taken in three parts (3.140625 + 9.675e-4 + 1.51e-7) by fused
+//        multiply-adds, |r| <= pi/2 (up to 2.3 near |x| = 2^23 where q can be one off),
+//   sin(r) = r + r*z*P(z), z = r*r, P of degree 4 (odd degree-11 minimax on [0, 2.3],
+//        polynomial error 2.4e-9), Horner with fused multiply-adds,
+//   result negated for odd q by xor with the parity bit moved to the sign position.
+// Checked against a double-precision sine on every float in [0, 2^23): largest absolute error
+// 1.41e-7 (1.25e-7 below 1e5), odd symmetry exact.  |x| >= 2^23 (where one float ulp is a
+// whole radian) or NaN -> +0.  GUARD = false is for callers that have already bounded |x| below
+// 2^23; for such x both forms return the same bits.
+constexpr float kSinRange = 8388608.0f;
 template <bool GUARD>
 WR_HD float wr_sin_t(float x) {
-    float ax = fabsf(x);
-    uint32_t sign = f2u(x) & 0x80000000u;
     if (GUARD) {
         // Branch-free: an out-of-range (or NaN) argument is replaced by +0 on entry, for
         // which the arithmetic below yields +0.
-        bool in_range = ax < 1073741824.0f;
-        ax = in_range ? ax : 0.0f;
-        sign = in_range ? sign : 0u;
+        x = fabsf(x) < kSinRange ? x : 0.0f;
     }
-    float y = ax * 1.27323954473516f;
-    int j = (int)y;
-    j = (j + 1) & ~1;
-    y = (float)j;
-    sign ^= ((uint32_t)(j & 4)) << 29;
-    float r = fmaf(y, -0.78515625f, ax);
-    r = fmaf(y, -2.4187564849853515625e-4f, r);
-    r = fmaf(y, -3.77489497744594108e-8f, r);
+    float qm = fmaf(x, 0.318309886183790672f, 12582912.0f);
+    float q = qm - 12582912.0f;
+    float r = fmaf(q, -3.140625f, x);
+    r = fmaf(q, -9.67502593994140625e-4f, r);
+    r = fmaf(q, -1.509957990978376432e-7f, r);
     float z = r * r;
-    float ps = -1.9515295891e-4f;
-    ps = fmaf(ps, z, 8.3321608736e-3f);
-    ps = fmaf(ps, z, -1.6666654611e-1f);
-    ps = ps * z;
-    ps = fmaf(ps, r, r);
-    float pc = 2.443315711809948e-5f;
-    pc = fmaf(pc, z, -1.388731625493765e-3f);
-    pc = fmaf(pc, z, 4.166664568298827e-2f);
-    pc = pc * z;
-    pc = pc * z;
-    pc = fmaf(z, -0.5f, pc);
-    pc = pc + 1.0f;
-    float res = (j & 2) ? pc : ps;
-    return u2f(f2u(res) ^ sign);
+    float p = -2.2534795035e-08f;
+    p = fmaf(p, z, 2.7403378113e-06f);
+    p = fmaf(p, z, -1.9836860877e-04f);
+    p = fmaf(p, z, 8.3332759288e-03f);
+    p = fmaf(p, z, -1.6666664062e-01f);
+    float t = z * r;
+    float res = fmaf(p, t, r);
+    return u2f(f2u(res) ^ (f2u(qm) << 31));
 }
 WR_HD float wr_sin(float x) { return wr_sin_t<true>(x); }
 
@@ -578,13 +574,24 @@ WR_HD V4 fs_pbr(const FrameConsts& fc, const ShadowMap& sm, const uint32_t* texe
 // ---------------------------------------------------------------------------------------
 // Fog: noise.wgsl + fog.wgsl.
 
+// fract(s) = s - floor(s).  The device's fraction instruction returns the same bits except
+// where s - floor(s) rounds up to 1.0 (a negative s of less than 2^-25 in magnitude), which
+// the noise hash cannot produce: its s is sin(d) * 42123.45 for the dot product d of an
+// integer lattice point, d is 0 or at least 2^-20 in magnitude, and for every float d with
+// 2^-20 <= |d| < 2^23 the difference stays below 1 (checked exhaustively).
+WR_HD float hash_fract(float s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fractf(s);
+#else
+    return s - floorf(s);
+#endif
+}
 // noise.wgsl:4 after the dot product: fract(sin(d) * 42123.45) * 2 - 1.  fr * 2 is exact,
 // so the fused form rounds once exactly where the two-step form rounds.
 template <bool GUARD>
 WR_HD float hash_from_dot(float d) {
     float s = wr_sin_t<GUARD>(d) * 42123.45f;
-    float fr = s - floorf(s);
-    return fmaf(fr, 2.0f, -1.0f);
+    return fmaf(hash_fract(s), 2.0f, -1.0f);
 }
 // smoothstep(0, 1, v) = t*t*(3 - 2t); 2t is exact, so fma(-2, t, 3) equals 3 - 2*t bit for bit.
 WR_HD float smooth01(float v) {
@@ -667,14 +674,19 @@ WR_HD float fbm_tab_t(V3 p, const NoiseTable* tabs) {
     return saturatef(ret);
 }
 // noise.wgsl:26-40.  The last octave samples p*128 and every hash argument is at most
-// (|q|+1) * (12.345 + 67.89 + 412.12); for |p| < 16000 that stays below 2^30, the sine's
-// range guard can never fire and the unguarded instantiation is used.
+// (|q|+1) * (12.345 + 67.89 + 412.12) (1 + 3*2^-24); for |p| < 133 that stays below 2^23
+// (8382346 < 8388608), the sine's range guard can never fire and the unguarded instantiation
+// is used.
+constexpr float kFbmUnguarded = 133.0f;
 WR_HD float fbm(V3 p) {
-    if (fabsf(p.x) < 16000.0f && fabsf(p.y) < 16000.0f && fabsf(p.z) < 16000.0f) return fbm_t<false>(p);  // false for NaN
+    if (fabsf(p.x) < kFbmUnguarded && fabsf(p.y) < kFbmUnguarded && fabsf(p.z) < kFbmUnguarded) return fbm_t<false>(p);  // false for NaN
     return fbm_t<true>(p);
 }
+// Tables are indexed through float -> int conversions, exact while |p| * 128 + 1 < 2^24.
+constexpr float kFbmTabled = 16000.0f;
 WR_HD float fbm_tab(V3 p, const NoiseTable* tabs) {
-    if (fabsf(p.x) < 16000.0f && fabsf(p.y) < 16000.0f && fabsf(p.z) < 16000.0f) return fbm_tab_t<false>(p, tabs);
+    if (fabsf(p.x) < kFbmUnguarded && fabsf(p.y) < kFbmUnguarded && fabsf(p.z) < kFbmUnguarded) return fbm_tab_t<false>(p, tabs);
+    if (fabsf(p.x) < kFbmTabled && fabsf(p.y) < kFbmTabled && fabsf(p.z) < kFbmTabled) return fbm_tab_t<true>(p, tabs);
     return fbm_t<true>(p);
 }
 // fog.wgsl:48-62
