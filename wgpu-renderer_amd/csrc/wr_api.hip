@@ -35,8 +35,8 @@ static_assert(sizeof(WrMaterialUniform) == 16, "MaterialUniform layout (material
 #define WR_COLOR_RASTER_THREADS 256
 #endif
 constexpr int kColorRasterThreads = WR_COLOR_RASTER_THREADS;
-constexpr size_t kNoiseLevelEntries = 16u << 20;  // largest hash table of one noise level
-constexpr size_t kNoisePoolEntries = 32u << 20;   // all levels together (128 MB per frame in flight)
+constexpr size_t kNoiseLevelEntries = 4u << 20;  // largest hash table of one noise level
+constexpr size_t kNoisePoolEntries = 8u << 20;    // all levels together (32 MB per frame in flight)
 static_assert(sizeof(FrameConsts) < 3072, "FrameConsts must fit the kernel argument segment");
 
 namespace {
