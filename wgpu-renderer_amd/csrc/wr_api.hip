@@ -579,7 +579,6 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
         ClearList cl{};
         cl.ptr[0] = f->geom.counters; cl.words[0] = (uint32_t)(f->geom.counters_bytes / 4);
         cl.ptr[1] = f->blend.counts; cl.words[1] = (uint32_t)(f->blend_clear_bytes / 4);
-        if (fog_pass) { cl.ptr[2] = f->fog.counters; cl.words[2] = (uint32_t)(f->fog.counters_bytes / 4); }
         hipLaunchKernelGGL(k_clear_words, dim3(8), dim3(256), 0, ms, cl);
     }
     VertexIn vin{g.pos, g.uv, g.nrm, g.tan, g.bit, g.nv};
@@ -595,12 +594,14 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
     if (prof) WR_HIP(hipEventRecord(ev[3], ms));
     WR_HIP(hipEventRecord(f->ev_geom_done, ms));
 
-    // side stream: fog volume set-up, noise tables, fog raster, march
+    // side stream: fog volume set-up and noise tables (they need the frame constants only),
+    // then, once the geometry depth exists, fog raster and march
     FogArgs fa;
     memset(&fa, 0, sizeof(fa));
-    WR_HIP(hipStreamWaitEvent(ss, f->ev_geom_done, 0));
-    if (prof) WR_HIP(hipEventRecord(ev[8], ss));
     if (fog_pass) {
+        ClearList cl{};
+        cl.ptr[0] = f->fog.counters; cl.words[0] = (uint32_t)(f->fog.counters_bytes / 4);
+        hipLaunchKernelGGL(k_clear_words, dim3(8), dim3(256), 0, ss, cl);
         hipLaunchKernelGGL(k_setup_small, grid1(fm.ntris), dim3(256), 0, ss, fm.pos, fm.idx, fm.ntris, 1, 1, 0u, f->fog.ws, fc);
         uint32_t max_entries = 0;
         fa.tables_noise = plan_noise_tables(ctx, f, fc, &max_entries);
@@ -613,6 +614,10 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
             }
             hipLaunchKernelGGL(k_fog_tables, dim3(plan.wg_begin[16]), dim3(256), 0, ss, fa.tables_noise, plan);
         }
+    }
+    WR_HIP(hipStreamWaitEvent(ss, f->ev_geom_done, 0));
+    if (prof) WR_HIP(hipEventRecord(ev[8], ss));
+    if (fog_pass) {
         fa.fc = fc; fa.ws = f->fog.ws; fa.pos = fm.pos; fa.idx = fm.idx; fa.ntris = fm.ntris;
         fa.depth = f->d_depth; fa.color = f->d_color; fa.shadow = f->d_shadow; fa.tables = ctx->d_tables;
         fa.counters = ctx->d_counters;
