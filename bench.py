@@ -54,7 +54,7 @@ PEAK_HBM_GBS = 8000.0
 # such a pass has been recorded for the current kernel.  (Algorithmic bytes of a launch: 20 B
 # read + 16 B written per work item = 24 MB; the rest is the 86 MB of noise tables and the shadow
 # map taps.)
-FOG_MARCH_HBM_BYTES = (2 * 50150 + 10420) * 1024  # profiles/r01_v4_pmc_hbm.txt
+FOG_MARCH_HBM_BYTES = (2 * 28120 + 10420) * 1024  # profiles/r01_v5_pmc_hbm.txt
 
 
 def build_scene(args):
