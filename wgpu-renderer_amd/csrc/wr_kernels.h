@@ -833,7 +833,10 @@ __device__ __attribute__((noinline)) uint32_t replay_pixel(const ShadeArgs& a, i
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
+// Six wavefronts per SIMD (at most 80 registers; the unconstrained allocation takes 88, i.e.
+// five): shading waits on dependent fetches for half of a wavefront's life, and the sixth
+// resident wavefront shortens the launch by 4 %; seven or eight would spill.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_shade(ShadeArgs a) {
     __shared__ uint32_t s_cnt, s_base;
     __shared__ float s_tab[768];
     // 16x16 pixels per workgroup, each wavefront an 8x8 block
@@ -962,7 +965,7 @@ __global__ __launch_bounds__(64) void k_replay_slow(ShadeArgs a) {
 
 // Ordered blending, step 3: one thread per fragment item runs pbr.wgsl's fs_main (the light
 // marker, drawn with REPLACE, has a constant colour: light_debug.wgsl:23-26).
-__global__ __launch_bounds__(64) void k_shade_frags(ShadeArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_shade_frags(ShadeArgs a) {
     __shared__ float s_tab[768];
     const BlendWS& bw = a.bw;
     if (blockIdx.x * 64u >= min(bw.counts[1], bw.frag_cap)) return;
