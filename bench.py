@@ -31,9 +31,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # Every frame in flight runs on its own pair of HIP streams; with HIP's default of four hardware
-# queues per process several of those streams share a queue and serialise (716 instead of 760
-# frames/s with four frames in flight).  Read by the HIP runtime when it initialises, so it is
-# set before anything touches the device.
+# queues per process several of those streams share a queue and run one after the other.  Read
+# by the HIP runtime when it initialises, so it is set before anything touches the device.
 if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 16:
     os.environ["GPU_MAX_HW_QUEUES"] = "16"
 
@@ -122,7 +121,7 @@ def main():
                     help="leave out the extra one-frame-in-flight pass after the timed region (for profiling runs)")
     ap.add_argument("--animate", action="store_true",
                     help="posebatch: t = time + k/60 for pose k (light, fog drift and shadow maps change every frame)")
-    ap.add_argument("--frames-in-flight", type=int, default=4, choices=[1, 2, 3, 4],
+    ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2, 3, 4],
                     help="sets of frame buffers the library alternates between (WrConfig.frames_in_flight)")
     args = ap.parse_args()
 

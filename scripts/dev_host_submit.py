@@ -33,11 +33,11 @@ def run(nfl, passes, label, sc):
 def main():
     sc = scene.sponza_standin(detail=1.0, tex_size=1024)
     full = abi.PASS_SHADOWS | abi.PASS_FOG | abi.PASS_LIGHT_DEBUG
-    if len(sys.argv) > 1:  # one case, for a profiler run: nofog | geom | full
+    if len(sys.argv) > 1:  # one case: nofog | geom | full [frames in flight]
         passes = {"nofog": abi.PASS_SHADOWS | abi.PASS_LIGHT_DEBUG, "geom": abi.PASS_LIGHT_DEBUG, "full": full}[sys.argv[1]]
-        run(4, passes, sys.argv[1], sc)
+        run(int(sys.argv[2]) if len(sys.argv) > 2 else 4, passes, sys.argv[1], sc)
         return
-    for nfl in (1, 4):
+    for nfl in (1, 2, 3, 4):
         run(nfl, full, "shadows + geometry + fog", sc)
         run(nfl, abi.PASS_SHADOWS | abi.PASS_LIGHT_DEBUG, "shadows + geometry", sc)
         run(nfl, abi.PASS_LIGHT_DEBUG, "geometry only", sc)
