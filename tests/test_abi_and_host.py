@@ -383,13 +383,31 @@ def _numeric_constants(text, decl):
     return out
 
 
+def test_wgsl_include_expansion(tmp_path):
+    # preprocessor.rs:6-23: top-level includes only, the whole line with its newline replaced
+    from wgpu_renderer_amd import wgsl
+    (tmp_path / "a.wgsl").write_text("#include c.wgsl\n#include g.wgsl\nfn main() {}\n")
+    (tmp_path / "c.wgsl").write_text("const K = 3;\n")
+    (tmp_path / "g.wgsl").write_text("#include c.wgsl\nstruct G { x: f32 }\n")
+    out = wgsl.preprocess_wgsl(str(tmp_path), "a.wgsl")
+    # only the top file's include lines are expanded, in their order: c.wgsl is pasted first,
+    # then g.wgsl, whose own "#include c.wgsl" line arrives after that replacement and stays
+    assert out == "const K = 3;\n#include c.wgsl\nstruct G { x: f32 }\nfn main() {}\n"
+
+
 def test_shader_constants_equal_the_reference_shaders():
-    """Every constant of the reference's constants.wgsl is present, under a recognisable name
-    and with the same value, in the device arithmetic and in the oracle."""
-    ref = "/root/reference/res/shaders/constants.wgsl"
-    if not os.path.exists(ref):
+    """Every constant of the reference's constants.wgsl, read from fog.wgsl and pbr.wgsl as the
+    reference's preprocessor flattens them, is present under a recognisable name and with the
+    same value in the device arithmetic and in the oracle."""
+    shader_dir = "/root/reference/res/shaders"
+    if not os.path.exists(os.path.join(shader_dir, "constants.wgsl")):
         pytest.skip("reference checkout not present")
-    wgsl = _numeric_constants(open(ref).read(), r"const")
+    from wgpu_renderer_amd import wgsl as wgsl_pre
+    fog_text = wgsl_pre.preprocess_wgsl(shader_dir, "fog.wgsl")
+    pbr_text = wgsl_pre.preprocess_wgsl(shader_dir, "pbr.wgsl")
+    assert "#include" not in fog_text and "#include" not in pbr_text
+    wgsl = _numeric_constants(fog_text, r"const")
+    assert wgsl == _numeric_constants(pbr_text, r"const")
     assert len(wgsl) >= 13 and wgsl["FOG_MAX_STEPS"] == [30.0]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     dev = {}
