@@ -42,10 +42,20 @@ def test_sine_accuracy_and_symmetry():
     xs = np.linspace(-20, 20, 4001, dtype=np.float32)
     got = np.array([L.wro_sin(float(x)) for x in xs])
     assert np.abs(got - np.sin(xs.astype(np.float64))).max() < 2e-7
-    for x in (0.3, 2.5, 1000.25, 123456.7):
+    # the whole range the rule serves: 1.41e-7 is the exhaustive maximum over [0, 2^23)
+    rng = np.random.default_rng(5)
+    big = np.concatenate([rng.uniform(-8388607.0, 8388607.0, 200000), np.arange(1, 100001) * np.pi]).astype(np.float32)
+    out = np.empty_like(big)
+    fp = C.POINTER(C.c_float)
+    L.wro_sin_many.argtypes = [fp, C.c_int, fp]
+    L.wro_sin_many(big.ctypes.data_as(fp), len(big), out.ctypes.data_as(fp))
+    assert np.abs(out.astype(np.float64) - np.sin(big.astype(np.float64))).max() < 1.45e-7
+    assert np.abs(out).max() <= 1.0
+    for x in (0.3, 2.5, 1000.25, 123456.7, 8.0e6):
         assert L.wro_sin(-x) == -L.wro_sin(x)
-    # large arguments stay bounded and deterministic; beyond 2^30 the rule says 0
-    assert abs(L.wro_sin(4.0e6)) <= 1.0 and L.wro_sin(2.0e9) == 0.0 and L.wro_sin(float("inf")) == 0.0
+    # large arguments stay bounded and deterministic; from 2^23 on the rule says 0
+    assert abs(L.wro_sin(4.0e6)) <= 1.0 and L.wro_sin(8388608.0) == 0.0 and L.wro_sin(2.0e9) == 0.0 and L.wro_sin(float("inf")) == 0.0
+    assert L.wro_sin(8388607.5) != 0.0 and np.isnan(L.wro_sin(float("nan"))) == False
 
 
 def test_rand_is_the_sin_hash():
