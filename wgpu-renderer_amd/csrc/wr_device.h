@@ -653,12 +653,31 @@ WR_HD float value_noise_tab(V3 p, const NoiseTable& t) {
     return value_noise_t<GUARD>(p);
 }
 
+// fbm returns saturate(sum); once the partial sum is so far below 0 (or above 1) that the
+// octaves still to come cannot bring it back, the result is known: 0 (or 1), the same bits
+// the full sum would saturate to.  What is still to come after octave i is at most
+// S_i = 2^-(i+1) - 2^-8 in magnitude times 1 + 4e-7 (a value_noise is three levels of mixes
+// of hashes in [-1, 1], each mix rounding three times) plus seven roundings of a sum of about
+// 1 (4.2e-7): less than S_i + 1e-6, and the test asks for 2e-6.  On the device the octaves
+// stop only when every lane of the wavefront is decided (lanes of one wavefront are
+// neighbouring pixels, and the low octaves that decide vary slowly in space); a decided lane
+// that runs on still saturates to the same value.  NaN decides nothing.
+WR_HD bool fbm_decided(float ret, int i) {
+    const float rest = (0.5f / (float)(1 << i)) - 0.00390625f + 2.0e-6f;  // S_i + 2e-6
+    const bool dec = ret <= -rest || ret >= 1.0f + rest;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __all(dec ? 1 : 0) != 0;
+#else
+    return dec;
+#endif
+}
 template <bool GUARD>
 WR_HD float fbm_t(V3 p) {
     float weight = 0.5f, ret = 0.0f;
     V3 q = p;
     for (int i = 0; i < 8; ++i) {
         ret += weight * value_noise_t<GUARD>(q);
+        if (i < 7 && fbm_decided(ret, i)) break;
         q = q * 2.0f;
         weight *= 0.5f;
     }
@@ -670,6 +689,7 @@ WR_HD float fbm_tab_t(V3 p, const NoiseTable* tabs) {
     V3 q = p;
     for (int i = 0; i < 8; ++i) {
         ret += weight * value_noise_tab<GUARD>(q, tabs[i]);
+        if (i < 7 && fbm_decided(ret, i)) break;
         q = q * 2.0f;
         weight *= 0.5f;
     }
