@@ -558,11 +558,23 @@ WR_HD V4 fs_pbr(const FrameConsts& fc, const ShadowMap& sm, const uint32_t* texe
     float light_dist = length3(lp - v3(in.wpos.x, in.wpos.y, in.wpos.z));
     float att = 1.0f / (1.0f + light_dist * light_dist);
     V3 direct = (v3(fc.light_color[0], fc.light_color[1], fc.light_color[2]) * fc.light_color[3]) * att;
-    float in_light = sample_direct_light(fc, sm, in.wpos);
+    float rs = fmaxf(sld, 0.0f);
+    V3 view_dir = normalize3(in.tview - in.tpos);
+    V3 half_dir = normalize3(view_dir + light_dir);
+    // A surface turned away from the light has rs = 0, and the shader's radiance * brdf is
+    // then (direct * 0) * in_light * brdf: a zero of either sign for any in_light as long as
+    // direct and brdf are finite, and 0 + (+-0) leaves total_radiance at +0, exactly what an
+    // unlit fragment gets.  The shadow lookup (six face tests, sixteen taps) is only made
+    // where its result can reach the pixel.
+    bool lookup = true;
+    if (!(rs > 0.0f)) {
+        V3 f = brdf(normal_dir, light_dir, view_dir, half_dir, albedo, roughness, metalness);
+        const float big = 3.0e38f;
+        lookup = !(fabsf(f.x) < big && fabsf(f.y) < big && fabsf(f.z) < big &&
+                   fabsf(direct.x) < big && fabsf(direct.y) < big && fabsf(direct.z) < big);
+    }
+    float in_light = lookup ? sample_direct_light(fc, sm, in.wpos) : 0.0f;
     if (in_light > 0.0f) {
-        V3 view_dir = normalize3(in.tview - in.tpos);
-        V3 half_dir = normalize3(view_dir + light_dir);
-        float rs = fmaxf(sld, 0.0f);
         V3 radiance = (direct * rs) * in_light;
         total = total + radiance * brdf(normal_dir, light_dir, view_dir, half_dir, albedo, roughness, metalness);
     }
