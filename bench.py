@@ -53,7 +53,13 @@ PEAK_HBM_GBS = 8000.0
 # such a pass has been recorded for the current kernel.  (Algorithmic bytes of a launch: 20 B
 # read + 16 B written per work item = 24 MB; the rest is the 86 MB of noise tables and the shadow
 # map taps.)
-FOG_MARCH_HBM_BYTES = (2 * 28120 + 10420) * 1024  # profiles/r01_v5_pmc_hbm.txt
+FOG_MARCH_HBM_BYTES = (2 * 27180 + 10420) * 1024  # profiles/r01_v7_pmc_hbm.txt
+# What the kernel executes for the default frame (the algorithmic count above prices octaves the
+# kernel reads from its tables or proves irrelevant as if they were evaluated): wave-level VALU
+# instructions of one launch, profiles/r01_v7_pmc_sq.txt, against the issue ceiling measured by
+# scripts/dev_ifetch_bench.hip (1.04 wave-instructions per ns and SIMD, 1024 SIMDs).
+FOG_MARCH_VALU_WAVE_INSTRUCTIONS = 4.175e8
+VALU_ISSUE_CEILING_PER_NS = 1.04 * 1024
 
 
 def build_scene(args):
@@ -121,7 +127,7 @@ def main():
                     help="leave out the extra one-frame-in-flight pass after the timed region (for profiling runs)")
     ap.add_argument("--animate", action="store_true",
                     help="posebatch: t = time + k/60 for pose k (light, fog drift and shadow maps change every frame)")
-    ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2, 3, 4],
+    ap.add_argument("--frames-in-flight", type=int, default=4, choices=[1, 2, 3, 4],
                     help="sets of frame buffers the library alternates between (WrConfig.frames_in_flight)")
     args = ap.parse_args()
 
@@ -267,6 +273,12 @@ def main():
                 "achieved": fog_flops / (march_alone_ms * 1e-3) / 1e12,
                 "frac": fog_flops / (march_alone_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS},
             "flop_per_launch": fog_flops,
+            "executed": None if not default_frame else {
+                "valu_wave_instructions_per_launch": FOG_MARCH_VALU_WAVE_INSTRUCTIONS,
+                "issue_ceiling_wave_instructions_per_ns": VALU_ISSUE_CEILING_PER_NS,
+                "issue_frac": FOG_MARCH_VALU_WAVE_INSTRUCTIONS / (fog_s * 1e9 * VALU_ISSUE_CEILING_PER_NS) if fog_s > 0 else None,
+                "issue_frac_one_frame_in_flight": None if not march_alone_ms else
+                FOG_MARCH_VALU_WAVE_INSTRUCTIONS / (march_alone_ms * 1e6 * VALU_ISSUE_CEILING_PER_NS)},
         }
         stage_ms = {"shadow": st.ms_shadow, "geometry": st.ms_geometry, "shade": st.ms_shade, "fog": st.ms_fog}
         hbm = {
