@@ -543,8 +543,7 @@ struct PbrInputs {
 
 // pbr.wgsl:73-130
 WR_HD V4 fs_pbr(const FrameConsts& fc, const ShadowMap& sm, const uint32_t* texels, const TexDesc* tex,
-                const MatDesc& m, const ColorTables& ct, const PbrInputs& in) {
-    V4 td = sample_material(texels, tex[m.base], ct, in.uv, in.ddx, in.ddy);
+                const MatDesc& m, const ColorTables& ct, const PbrInputs& in, V4 td) {  // td: the base-colour sample
     V4 tn = sample_material(texels, tex[m.normal], ct, in.uv, in.ddx, in.ddy);
     V4 trm = sample_material(texels, tex[m.mr], ct, in.uv, in.ddx, in.ddy);
     V3 albedo = v3(td.x, td.y, td.z);

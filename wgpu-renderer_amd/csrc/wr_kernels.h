@@ -737,6 +737,11 @@ __device__ inline void stage_color_tables(float* s_tab, const float* tables) {
 // Interpolates the VertexOutput of one fragment and runs pbr.wgsl's fs_main on it.
 // Derivatives for the sampler's level of detail are taken per 2x2 quad on the fragment's
 // own triangle: ddx = uv(x0+1,y0) - uv(x0,y0), ddy = uv(x0,y0+1) - uv(x0,y0).
+// ALPHA_FIRST is for k_shade, which only keeps the colour of a fragment whose alpha is 1 (any
+// other front-most fragment goes to the ordered-blend kernels, which shade it again in its
+// place in the draw order): alpha is the base-colour texel's, so a fragment with another alpha
+// returns after that one texture sample, colour unset.
+template <bool ALPHA_FIRST>
 __device__ inline V4 shade_fragment(const ShadeArgs& a, const float* color_tables, const Rec& r, const float* beta,
                                     const Edges& e, uint32_t tri, int px, int py, const int64_t* E) {
     uint32_t i0 = a.idx[3 * tri], i1 = a.idx[3 * tri + 1], i2 = a.idx[3 * tri + 2];
@@ -756,6 +761,10 @@ __device__ inline V4 shade_fragment(const ShadeArgs& a, const float* color_table
     }
     in.ddx = V2{q[1].x - q[0].x, q[1].y - q[0].y};
     in.ddy = V2{q[2].x - q[0].x, q[2].y - q[0].y};
+    ColorTables ct{color_tables};
+    const MatDesc& m = a.mats[a.tri_mat[tri]];
+    const V4 td = sample_material(a.texels, a.tex[m.base], ct, in.uv, in.ddx, in.ddy);
+    if (ALPHA_FIRST && td.w != 1.0f) return V4{0.0f, 0.0f, 0.0f, td.w};
     float4 b0 = a.v1[i0], b1 = a.v1[i1], b2 = a.v1[i2];
     float4 c0 = a.v2[i0], c1 = a.v2[i1], c2 = a.v2[i2];
     float4 d0 = a.v3[i0], d1 = a.v3[i1], d2 = a.v3[i2];
@@ -764,8 +773,7 @@ __device__ inline V4 shade_fragment(const ShadeArgs& a, const float* color_table
     in.tview = v3(ip(B, c0.x, c1.x, c2.x), ip(B, c0.y, c1.y, c2.y), ip(B, c0.z, c1.z, c2.z));
     in.wpos = V4{ip(B, c0.w, c1.w, c2.w), ip(B, d0.x, d1.x, d2.x), ip(B, d0.y, d1.y, d2.y), ip(B, d0.z, d1.z, d2.z)};
     ShadowMap sm{a.shadow, a.fc.S};
-    ColorTables ct{color_tables};
-    return fs_pbr(a.fc, sm, a.texels, a.tex, a.mats[a.tri_mat[tri]], ct, in);
+    return fs_pbr(a.fc, sm, a.texels, a.tex, m, ct, in, td);
 }
 
 // Resolves (triangle id, fan index) to its record and clip weights.
@@ -823,7 +831,7 @@ __device__ __attribute__((noinline)) uint32_t replay_pixel(const ShadeArgs& a, i
             make_edges(r, e);
             int64_t E[3];
             edge_eval(e, px, py, E);
-            V4 src = shade_fragment(a, a.tables, r, beta, e, tri, px, py, E);
+            V4 src = shade_fragment<false>(a, a.tables, r, beta, e, tri, px, py, E);
             col = blend_pack(ct, col, src, true);
         }
         d = best_z;
@@ -863,7 +871,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         make_edges(r, e);
         int64_t E[3];
         edge_eval(e, px, py, E);
-        V4 src = shade_fragment(a, s_tab, r, beta, e, tri, px, py, E);
+        V4 src = shade_fragment<true>(a, s_tab, r, beta, e, tri, px, py, E);
         if (COUNT) atomicAdd(&a.counters[2], 1ull);
         if (src.w == 1.0f) {
             a.color[pi] = blend_pack(ct, 0u, src, false);  // alpha 1 replaces whatever was blended before
@@ -985,7 +993,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
             make_edges(r, e);
             int64_t E[3];
             edge_eval(e, px, py, E);
-            src = shade_fragment(a, s_tab, r, beta, e, tri, px, py, E);
+            src = shade_fragment<false>(a, s_tab, r, beta, e, tri, px, py, E);
         }
         bw.frag_src[f] = make_float4(src.x, src.y, src.z, src.w);
     }
