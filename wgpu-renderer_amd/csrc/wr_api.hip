@@ -35,6 +35,10 @@ static_assert(sizeof(WrMaterialUniform) == 16, "MaterialUniform layout (material
 #define WR_COLOR_RASTER_THREADS 256
 #endif
 constexpr int kColorRasterThreads = WR_COLOR_RASTER_THREADS;
+#ifndef WR_SHADOW_RASTER_THREADS
+#define WR_SHADOW_RASTER_THREADS 256
+#endif
+constexpr int kShadowRasterThreads = WR_SHADOW_RASTER_THREADS;
 constexpr size_t kNoiseLevelEntries = 4u << 20;  // largest hash table of one noise level
 constexpr size_t kNoisePoolEntries = 8u << 20;    // all levels together (32 MB per frame in flight)
 static_assert(sizeof(FrameConsts) < 3072, "FrameConsts must fit the kernel argument segment");
@@ -402,7 +406,7 @@ int bin_and_raster(WrContext* ctx, FrameRes* f, hipStream_t st, WsAlloc& w, bool
     hipLaunchKernelGGL(k_bin_fill, grid1(nrec, ws.layers), dim3(256), 0, st, ws, tr, tw);
     dim3 g((uint32_t)(ws.bins_x * ws.bins_y), (uint32_t)ws.layers, 1);
     if (shadow)
-        hipLaunchKernelGGL((k_raster<kRasterShadow, 256>), g, dim3(256), 0, st, ws, ctx->S, ctx->S, (uint32_t*)nullptr,
+        hipLaunchKernelGGL((k_raster<kRasterShadow, kShadowRasterThreads>), g, dim3(kShadowRasterThreads), 0, st, ws, ctx->S, ctx->S, (uint32_t*)nullptr,
                            f->d_shadow, 0, 1, LayerSink{});
     else
         hipLaunchKernelGGL((k_raster<kRasterColor, kColorRasterThreads>), g, dim3(kColorRasterThreads), 0, st, ws, ctx->W, ctx->H, f->d_vis,
