@@ -257,9 +257,10 @@ int wr_get_stats(WrContext* ctx, WrFrameStats* out);
  * their quirks: one mesh per primitive in document order, node transforms ignored,
  * tangent = TANGENT.xyz * w, bitangent = normal x tangent, NaN tangents without TANGENT,
  * missing texture slots fall back to image 0, RGB padded to RGBA, base colour sRGB and the
- * other two maps linear, primitive.material defaults to 0.  Embedded 8-bit PNG images are
- * decoded; JPEG, 16-bit and grey images return WR_ERR_UNSUPPORTED (the reference panics on the
- * last two, resources.rs:51,138-151).  Parsing touches no device. */
+ * other two maps linear, primitive.material defaults to 0.  Embedded 8-bit PNG and JPEG
+ * (baseline, extended sequential, progressive; three components) images are decoded; 16-bit,
+ * grey and CMYK images return WR_ERR_UNSUPPORTED (the reference panics on 16-bit and grey
+ * ones, resources.rs:51,138-151).  Parsing touches no device. */
 typedef struct WrGlb WrGlb;
 int wr_glb_parse(const void* data, size_t bytes, WrGlb** out, char* err, size_t err_cap);
 int wr_glb_load_file(const char* path, WrGlb** out, char* err, size_t err_cap);

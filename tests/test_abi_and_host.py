@@ -430,3 +430,100 @@ def test_shader_constants_equal_the_reference_shaders():
         oname = "PI_C" if name == "PI" else name
         assert [float(np.float32(x)) for x in orc[oname]] == f32, name
         assert [float(np.float32(x)) for x in dev[camel(name)]] == f32, name
+
+
+def _image_only_glb(image_bytes):
+    """A GLB that holds nothing but one embedded image (and a material that names it)."""
+    import json
+    import struct
+    bb = image_bytes + b"\0" * (-len(image_bytes) % 4)
+    js = {"asset": {"version": "2.0"}, "buffers": [{"byteLength": len(bb)}],
+          "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": len(image_bytes)}],
+          "images": [{"bufferView": 0}], "textures": [{"source": 0}],
+          "materials": [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}}]}
+    jb = json.dumps(js).encode()
+    jb += b" " * (-len(jb) % 4)
+    return struct.pack("<4sII", b"glTF", 2, 12 + 8 + len(jb) + 8 + len(bb)) + struct.pack("<I4s", len(jb), b"JSON") + jb + struct.pack("<I4s", len(bb), b"BIN\0") + bb
+
+
+def _test_picture(rng, w, h):
+    """Smooth gradients, a few hard edges and some noise: exercises DC, low and high AC."""
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = np.stack([127 + 120 * np.sin(x / 9.0 + y / 23.0), 127 + 120 * np.cos(y / 7.0), 40 + 200 * ((x // 16 + y // 16) % 2)], axis=2)
+    img += rng.normal(0, 6, img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("subsampling,progressive,size", [
+    ("4:4:4", False, (64, 48)), ("4:2:2", False, (67, 45)), ("4:2:0", False, (129, 70)),
+    ("4:2:0", True, (96, 80)), ("4:4:4", True, (33, 17)), ("4:2:0", False, (1, 1)), ("4:2:2", True, (200, 9))])
+def test_native_jpeg_decode_is_close_to_libjpeg(subsampling, progressive, size):
+    """JPEG textures through the native importer against PIL (libjpeg).  The two decoders use
+    different inverse transforms and upsampling filters, so texels agree closely, not bit for
+    bit; the reference's own decoder (jpeg-decoder 0.3.0) is not in the checkout: unpinned."""
+    import io
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(3)
+    w, h = size
+    src = _test_picture(rng, w, h)
+    buf = io.BytesIO()
+    PIL.fromarray(src, "RGB").save(buf, "JPEG", quality=92, subsampling=subsampling, progressive=progressive, optimize=progressive)
+    data = buf.getvalue()
+    want = np.asarray(PIL.open(io.BytesIO(data)).convert("RGB"))
+    g = abi.Glb(data=_image_only_glb(data))
+    got, srgb = g.texture(0)
+    assert srgb and got.shape == (h, w, 4) and np.all(got[..., 3] == 255)
+    diff = np.abs(got[..., :3].astype(np.int32) - want.astype(np.int32))
+    assert diff.mean() < 0.5 and diff.max() <= 8, (diff.mean(), diff.max())
+    # and both are decodes of the picture that was encoded
+    assert np.abs(got[..., :3].astype(np.int32) - src.astype(np.int32)).mean() < np.abs(want.astype(np.int32) - src.astype(np.int32)).mean() + 0.5
+
+
+def test_native_jpeg_decode_with_restart_markers_and_errors():
+    import io
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(4)
+    src = _test_picture(rng, 80, 56)
+    buf = io.BytesIO()
+    PIL.fromarray(src, "RGB").save(buf, "JPEG", quality=85, subsampling="4:2:0", restart_marker_blocks=3)
+    data = buf.getvalue()
+    assert b"\xff\xdd" in data  # DRI present
+    want = np.asarray(PIL.open(io.BytesIO(data)).convert("RGB"))
+    got, _ = abi.Glb(data=_image_only_glb(data)).texture(0)
+    diff = np.abs(got[..., :3].astype(np.int32) - want.astype(np.int32))
+    assert diff.mean() < 0.5 and diff.max() <= 8
+    # a grey JPEG has one channel: resources.rs:51 asserts 3 or 4
+    buf = io.BytesIO()
+    PIL.fromarray(src[..., 0], "L").save(buf, "JPEG")
+    with pytest.raises(abi.WrError) as e:
+        abi.Glb(data=_image_only_glb(buf.getvalue()))
+    assert e.value.code == abi.WR_ERR_UNSUPPORTED
+    # truncated data is an error, not a crash
+    with pytest.raises(abi.WrError):
+        abi.Glb(data=_image_only_glb(data[: len(data) // 3]))
+
+
+def test_native_jpeg_decode_survives_corrupt_streams():
+    """Flipped bytes and cuts anywhere in a baseline and in a progressive stream: the importer
+    either decodes something or reports an error; it never reads outside the buffer (the
+    library runs inside the caller's process)."""
+    import io
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(6)
+    src = _test_picture(rng, 48, 40)
+    for progressive in (False, True):
+        buf = io.BytesIO()
+        PIL.fromarray(src, "RGB").save(buf, "JPEG", quality=80, subsampling="4:2:0", progressive=progressive)
+        good = bytearray(buf.getvalue())
+        for trial in range(150):
+            bad = bytearray(good)
+            for _ in range(int(rng.integers(1, 6))):
+                bad[int(rng.integers(2, len(bad)))] = int(rng.integers(0, 256))
+            if trial % 3 == 0:
+                bad = bad[: int(rng.integers(4, len(bad)))]
+            try:
+                g = abi.Glb(data=_image_only_glb(bytes(bad)))
+                px, _ = g.texture(0)
+                assert px.ndim == 3 and px.shape[2] == 4
+            except abi.WrError as e:
+                assert e.code in (abi.WR_ERR_INVALID_ARGUMENT, abi.WR_ERR_UNSUPPORTED)

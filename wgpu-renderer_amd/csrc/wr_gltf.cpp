@@ -12,9 +12,10 @@
 //   * base colour is sRGB, normal and metallic-roughness are linear (resources.rs:62,89,116);
 //   * primitive.material defaults to 0 (mesh.rs:23).
 // Images: PNG (8-bit RGB / RGBA / palette, not interlaced) is decoded here with zlib; where
-// the reference uses the `image` crate the decoded texels are the same bytes.  JPEG is not
-// decoded (WR_ERR_UNSUPPORTED): a host with such assets decodes them itself and calls
-// wr_upload_texture.  Pure host code: nothing here touches the device.
+// the reference uses the `image` crate the decoded texels are the same bytes.  JPEG (baseline,
+// extended sequential and progressive, three components) goes through wr_jpeg.cpp, whose
+// texels are close to, but not pinned to, the reference's decoder.  Pure host code: nothing
+// here touches the device.
 
 #include <zlib.h>
 
@@ -29,6 +30,8 @@
 #include <vector>
 
 #include "../../include/wr_abi.h"
+
+int wr_decode_jpeg(const uint8_t* data, size_t n, uint32_t* w, uint32_t* h, std::vector<uint8_t>& rgba, std::string& err);
 
 namespace {
 
@@ -424,8 +427,9 @@ int parse_glb(const uint8_t* data, size_t bytes, WrGlb& g, std::string& err) {
             size_t o = (size_t)bv.integer("byteOffset", 0), len = (size_t)bv.integer("byteLength", 0);
             if (o + len > bin.size()) { err = "glb: image exceeds the buffer"; return WR_ERR_INVALID_ARGUMENT; }
             Image im;
-            if (len >= 3 && bin[o] == 0xFF && bin[o + 1] == 0xD8) { err = "glb: JPEG images are not decoded by this loader"; return WR_ERR_UNSUPPORTED; }
-            int rc = decode_png(bin.data() + o, len, im, err);
+            int rc;
+            if (len >= 3 && bin[o] == 0xFF && bin[o + 1] == 0xD8) rc = wr_decode_jpeg(bin.data() + o, len, &im.w, &im.h, im.rgba, err);
+            else rc = decode_png(bin.data() + o, len, im, err);
             if (rc != WR_OK) return rc;
             g.images.push_back(std::move(im));
         }
