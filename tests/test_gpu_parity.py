@@ -147,9 +147,12 @@ def test_camera_poses(small_scene, pose):
     assert_parity(g, o)
 
 
-@pytest.mark.parametrize("t", [0.0, 7.3, 123.0])
+@pytest.mark.parametrize("t", [0.0, 7.3, 123.0, 400.0, 90000.0])
 def test_light_animation_times(tiny_scene, t):
-    # t = 0 is the black light (|sin 0| = 0, state.rs:615-617); larger t moves light and fog drift
+    # t = 0 is the black light (|sin 0| = 0, state.rs:615-617); larger t moves light and fog drift.
+    # The fog drift 0.2 t also moves the noise domain: at t = 400 the finest octaves' hash
+    # arguments pass 2^23, where the sine rule returns 0 and the range-checked instantiation of
+    # the noise runs; at t = 90000 the domain is beyond what the hash tables index.
     w, h, s = 256, 144, 256
     cam, light, glob = default_inputs(w, h, t=t)
     g = render_gpu(tiny_scene, cam, light, glob, abi.PASS_ALL, w, h, s)
