@@ -613,8 +613,9 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
             TablePlan plan{};
             for (int l = 0; l < 16; ++l) {
                 const NoiseTable& t = fa.tables_noise.level[l];
-                plan.chunks[l] = t.data ? ((uint32_t)t.nx + 255u) / 256u : 1u;
-                plan.wg_begin[l + 1] = plan.wg_begin[l] + (t.data ? plan.chunks[l] * (uint32_t)t.ny * (uint32_t)t.nz : 0u);
+                plan.xchunks[l] = plan.ychunks[l] = 1u;
+                plan.wg_begin[l + 1] = plan.wg_begin[l];
+                if (t.data) plan_table_level(plan, l, t.nx, t.ny, t.nz);
             }
             hipLaunchKernelGGL(k_fog_tables, dim3(plan.wg_begin[16]), dim3(256), 0, ss, fa.tables_noise, plan);
         }

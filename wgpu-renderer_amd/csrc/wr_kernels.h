@@ -1224,12 +1224,25 @@ __global__ __launch_bounds__(64) void k_fog_multi(FogArgs a) {
 }
 
 // Fills the hash tables: entry (i,j,k) of a level = hash of lattice point lo + (i,j,k).  The
-// workgroups of all levels form one grid; a workgroup takes up to 256 consecutive x of one
-// (y, z) row of its level, so a thread decodes no index.
+// workgroups of all levels form one grid.  A workgroup covers a tile of one z slice: 2^xshift
+// consecutive x (the power of two that holds the row, at most 256) by 256 >> xshift
+// consecutive y, so narrow tables still fill their wavefronts and a thread decodes its index
+// with shifts only.
 struct TablePlan {
     uint32_t wg_begin[17];  // first workgroup of each level (level l owns [wg_begin[l], wg_begin[l+1]))
-    uint32_t chunks[16];    // workgroups per row = ceil(nx / 256)
+    uint32_t xchunks[16];   // tiles per row = ceil(nx / 2^xshift)
+    uint32_t ychunks[16];   // tiles per column = ceil(ny / (256 >> xshift))
+    uint32_t xshift[16];
 };
+__host__ inline void plan_table_level(TablePlan& plan, int l, int nx, int ny, int nz) {
+    uint32_t sh = 0;
+    while (sh < 8 && (1u << sh) < (uint32_t)nx) ++sh;
+    const uint32_t xw = 1u << sh, yr = 256u >> sh;
+    plan.xshift[l] = sh;
+    plan.xchunks[l] = ((uint32_t)nx + xw - 1u) / xw;
+    plan.ychunks[l] = ((uint32_t)ny + yr - 1u) / yr;
+    plan.wg_begin[l + 1] = plan.wg_begin[l] + plan.xchunks[l] * plan.ychunks[l] * (uint32_t)nz;
+}
 __global__ __launch_bounds__(256) void k_fog_tables(NoiseTables nt, TablePlan plan) {
     const uint32_t b = blockIdx.x;
     int level = 0;
@@ -1237,10 +1250,13 @@ __global__ __launch_bounds__(256) void k_fog_tables(NoiseTables nt, TablePlan pl
     const NoiseTable t = nt.level[level];
     if (t.data == nullptr || b >= plan.wg_begin[level + 1]) return;
     const uint32_t local = b - plan.wg_begin[level];
-    const uint32_t row = local / plan.chunks[level], chunk = local % plan.chunks[level];
-    const int iy = (int)(row % (uint32_t)t.ny), iz = (int)(row / (uint32_t)t.ny);
-    const int ix = (int)(chunk * 256u + threadIdx.x);
-    if (ix >= t.nx) return;
+    const uint32_t xc = local % plan.xchunks[level], rest = local / plan.xchunks[level];
+    const uint32_t yc = rest % plan.ychunks[level];
+    const int iz = (int)(rest / plan.ychunks[level]);
+    const uint32_t sh = plan.xshift[level];
+    const int ix = (int)((xc << sh) + (threadIdx.x & ((1u << sh) - 1u)));
+    const int iy = (int)(yc * (256u >> sh) + (threadIdx.x >> sh));
+    if (ix >= t.nx || iy >= t.ny) return;
     const size_t i = ((size_t)iz * t.ny + iy) * t.nx + ix;
     const_cast<float*>(t.data)[i] = lattice_hash((float)(t.lox + ix), (float)(t.loy + iy), (float)(t.loz + iz));
 }
