@@ -391,6 +391,10 @@ FrameConsts make_consts(const WrContext* ctx, const WrCameraUniform* cam, const 
     fc.drift_xy = glob->time * 0.2f;
     fc.drift_z = wr_sin(glob->time * 0.1f) * 0.5f;
     fc.use_shadowmaps = glob->use_shadowmaps;
+    fc.light_tame = 1u;
+    for (int i = 0; i < 6; ++i)
+        for (int k = 0; k < 16; ++k)
+            if (!(std::fabs(fc.light_m[i][k]) < 1.0e15f)) fc.light_tame = 0u;
     fc.W = ctx->W; fc.H = ctx->H; fc.S = ctx->S;
     fc.tile_rank = (int)ctx->cfg.tile_rank;
     fc.tile_world = (int)(ctx->cfg.tile_world ? ctx->cfg.tile_world : 1);

@@ -132,6 +132,7 @@ struct FrameConsts {
     float drift_xy;          // time * 0.2            (fog.wgsl:50-51)
     float drift_z;           // sin(time*0.1) * 0.5   (fog.wgsl:52)
     uint32_t use_shadowmaps;
+    uint32_t light_tame;     // every entry of light_m is finite and below 1e15 in magnitude
     int W, H, S;
     int tile_rank, tile_world;
 };
@@ -488,7 +489,17 @@ WR_HD float sample_direct_light_index(const ShadowMap& sm, int index, V4 lc) {
 WR_HD float sample_direct_light(const FrameConsts& fc, const ShadowMap& sm, V4 wp) {
     float in_light = 0.0f;
     if (fc.use_shadowmaps > 0u) {
+        // With matrix entries and position below 1e15 the light-space position is finite, so a
+        // negative z gives ld.z = z * (1 / length) in [-inf, -0] (length > 0, possibly
+        // overflowed to inf): below the first threshold, the face is skipped.  The three faces
+        // that look away from the point take this exit before the rest of the product and the
+        // normalisation are worked out.
+        const float lim = 1.0e15f;
+        const bool tame = fc.light_tame != 0u && fabsf(wp.x) < lim && fabsf(wp.y) < lim && fabsf(wp.z) < lim && fabsf(wp.w) < lim;
         for (int i = 0; i < 6; ++i) {
+            const float* m = fc.light_m[i];
+            const float lz = ((m[2] * wp.x + m[6] * wp.y) + m[10] * wp.z) + m[14] * wp.w;  // mat4_mul(m, wp).z
+            if (tame && lz < 0.0f) continue;
             V4 lc = mat4_mul(fc.light_m[i], wp);
             V3 ld = normalize3(v3(lc.x, lc.y, lc.z));
             if (ld.z < kInvSqrt3 - 0.01f) continue;
