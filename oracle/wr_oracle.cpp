@@ -21,11 +21,16 @@
 //  R2  normalize(v) = v * (1/sqrt(dot(v,v))) ; length = sqrt(dot).
 //  R3  mix(a,b,t) = a*(1-t) + b*t ; smoothstep(0,1,v): t = clamp(v,0,1), t*t*(3-2t);
 //      fract(x) = x - floor(x) ; saturate = min(max(x,0),1).
-//  R4  sin: q = x/pi rounded to an integer by fma(x, 1/pi, 1.5*2^23) - 1.5*2^23; r = x - q*pi
-//      with pi in three parts (3.140625 + 9.675e-4 + 1.51e-7) by fused multiply-adds;
-//      sin r = r + r*z*P(z), z = r*r, P of degree 4 (minimax on [0, 2.3]), fused Horner steps;
-//      negated when q is odd.  Largest absolute error against a double-precision sine over
-//      every float in [0, 2^23): 1.41e-7.  |x| >= 2^23 or NaN gives +0.
+//  R4  sin = single-precision Cephes sinf as sse_mathfun's sin_ps has it and Mesa's gallivm
+//      (lp_build_sin_or_cos, the lowering lavapipe runs for SPIR-V Sin) follows it: octant
+//      j = (trunc(|x|*4/pi) + 1) & ~1, r = |x| - j*pi/4 with pi/4 in three parts
+//      (0.78515625, 2.4187564849853515625e-4, 3.77489497744594108e-8), degree-3 polynomials
+//      in z = r*r for sine (j&2 == 0) and cosine, sign = sign(x) ^ (j&4); fused multiply-adds
+//      in the reduction and the Horner steps; |x| >= 2^30 or NaN gives +0.  Mesa's source is
+//      not in this image: the constants and the step order are restated from the published
+//      Cephes / sse_mathfun code, unpinned against a lavapipe run.  A rule of this list
+//      changes only on evidence from the reference or from the specifications it runs on,
+//      never for speed.
 //  R5  pow(b, 5.0) = (b*b)*(b*b)*b.
 //  R6  clip volume: -w<=x,y<=w, 0<=z<=w.  A triangle with all vertices outside one plane
 //      is dropped.  A triangle with any vertex with z<0, z>w, |x|>8w or |y|>8w is clipped
@@ -120,23 +125,39 @@ inline V3 mul(const M3& m, V3 v) {
 inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
-// R4.  The rounded quotient q sits in the low mantissa bits of qm, so its parity is bit 0.
+// R4: single-precision Cephes sine (the scheme of sse_mathfun's sin_ps, which Mesa's gallivm
+// lowers fsin to), fused multiply-adds in the reduction and the Horner steps.
 float o_sin(float x) {
-    if (!(fabsf(x) < 8388608.0f)) return 0.0f;
-    const float magic = 12582912.0f;  // 1.5 * 2^23
-    float qm = fmaf(x, 0.318309886183790672f, magic);
-    float q = qm - magic;
-    float r = fmaf(q, -3.140625f, x);
-    r = fmaf(q, -9.67502593994140625e-4f, r);
-    r = fmaf(q, -1.509957990978376432e-7f, r);
+    uint32_t sign = f2u(x) & 0x80000000u;
+    float ax = fabsf(x);
+    if (!(ax < 1073741824.0f)) return 0.0f;
+    float y = ax * 1.27323954473516f;  // 4/pi
+    int j = (int)y;
+    j = (j + 1) & ~1;
+    y = (float)j;
+    sign ^= ((uint32_t)(j & 4)) << 29;
+    bool sin_poly = (j & 2) == 0;
+    float r = fmaf(y, -0.78515625f, ax);
+    r = fmaf(y, -2.4187564849853515625e-4f, r);
+    r = fmaf(y, -3.77489497744594108e-8f, r);
     float z = r * r;
-    float p = fmaf(-2.2534795035e-08f, z, 2.7403378113e-06f);
-    p = fmaf(p, z, -1.9836860877e-04f);
-    p = fmaf(p, z, 8.3332759288e-03f);
-    p = fmaf(p, z, -1.6666664062e-01f);
-    float res = fmaf(p, z * r, r);
-    bool odd = (f2u(qm) & 1u) != 0;
-    return odd ? -res : res;
+    float res;
+    if (sin_poly) {
+        float p = -1.9515295891e-4f;
+        p = fmaf(p, z, 8.3321608736e-3f);
+        p = fmaf(p, z, -1.6666654611e-1f);
+        p = p * z;
+        res = fmaf(p, r, r);
+    } else {
+        float p = 2.443315711809948e-5f;
+        p = fmaf(p, z, -1.388731625493765e-3f);
+        p = fmaf(p, z, 4.166664568298827e-2f);
+        p = p * z;
+        p = p * z;
+        p = fmaf(z, -0.5f, p);
+        res = p + 1.0f;
+    }
+    return u2f(f2u(res) ^ sign);
 }
 
 // ------------------------------------------------------------------------- noise.wgsl
@@ -1025,6 +1046,18 @@ float wro_sin(float x) { return o_sin(x); }
 void wro_sin_many(const float* x, int n, float* out) { for (int i = 0; i < n; ++i) out[i] = o_sin(x[i]); }
 // rand of noise.wgsl:3-5 from the value of its dot product
 void wro_hash_many(const float* d, int n, float* out) { for (int i = 0; i < n; ++i) out[i] = o_hash_of_dot(d[i]); }
+// Floats d with bit patterns in [lo_bits, hi_bits) (positive d; both signs are tried) for which
+// the hash's s - floor(s) is not below 1, i.e. where a hardware fraction instruction (which
+// returns the float below 1 there) would differ from the written formula.
+uint64_t wro_hash_fract_exceptions(uint32_t lo_bits, uint32_t hi_bits, uint32_t stride, uint32_t phase) {
+    uint64_t bad = 0;
+    for (uint64_t b = (uint64_t)lo_bits + phase; b < hi_bits; b += stride)
+        for (uint32_t sg = 0; sg < 2; ++sg) {
+            float s = o_sin(u2f((uint32_t)b | (sg << 31))) * 42123.45f;
+            if (!(s - floorf(s) < 1.0f)) ++bad;
+        }
+    return bad;
+}
 float wro_rand(const float p[3]) { return o_rand(v3(p[0], p[1], p[2])); }
 float wro_value_noise(const float p[3]) { return o_value_noise(v3(p[0], p[1], p[2])); }
 float wro_fbm(const float p[3]) { return o_fbm(v3(p[0], p[1], p[2])); }

@@ -38,24 +38,77 @@ def bits(x):
 
 
 # ------------------------------------------------------------------ unit formulas
+def cephes_sinf_numpy(x):
+    """Rule R4 restated with numpy float32 scalars (no shared code with the C++): the published
+    single-precision Cephes / sse_mathfun sine.  Fused steps are done in float64 and rounded
+    once, which equals an fma whenever the float64 product-sum is exact enough; the test below
+    only uses it where that holds (|x| small enough that y * DP fits 53 bits)."""
+    f = np.float32
+    sign = x < 0
+    ax = f(abs(x))
+    y = f(ax * f(1.27323954473516))
+    j = (int(y) + 1) & ~1
+    y = f(j)
+    if j & 4:
+        sign = not sign
+    fma = lambda a, b, c: f(np.float64(a) * np.float64(b) + np.float64(c))
+    r = fma(y, f(-0.78515625), ax)
+    r = fma(y, f(-2.4187564849853515625e-4), r)
+    r = fma(y, f(-3.77489497744594108e-8), r)
+    z = f(r * r)
+    if j & 2 == 0:
+        p = fma(f(-1.9515295891e-4), z, f(8.3321608736e-3))
+        p = fma(p, z, f(-1.6666654611e-1))
+        p = f(p * z)
+        res = fma(p, r, r)
+    else:
+        p = fma(f(2.443315711809948e-5), z, f(-1.388731625493765e-3))
+        p = fma(p, z, f(4.166664568298827e-2))
+        p = f(f(p * z) * z)
+        p = fma(z, f(-0.5), p)
+        res = f(p + f(1.0))
+    return f(-res) if sign else f(res)
+
+
 def test_sine_accuracy_and_symmetry():
     xs = np.linspace(-20, 20, 4001, dtype=np.float32)
     got = np.array([L.wro_sin(float(x)) for x in xs])
-    assert np.abs(got - np.sin(xs.astype(np.float64))).max() < 2e-7
-    # the whole range the rule serves: 1.41e-7 is the exhaustive maximum over [0, 2^23)
-    rng = np.random.default_rng(5)
+    assert np.abs(got - np.sin(xs.astype(np.float64))).max() < 1.2e-7
+    # the numpy restatement of the published algorithm agrees bit for bit
+    rng = np.random.default_rng(9)
+    for x in np.concatenate([xs[::40], rng.uniform(-3e4, 3e4, 400).astype(np.float32)]):
+        assert bits(L.wro_sin(float(x))) == bits(cephes_sinf_numpy(np.float32(x))), float(x)
+    # arguments the noise hash reaches (lattice dot products up to millions): the three-part
+    # reduction keeps the error at a few 1e-7 (exhaustive maximum over [0, 2^23): 1.77e-7)
     big = np.concatenate([rng.uniform(-8388607.0, 8388607.0, 200000), np.arange(1, 100001) * np.pi]).astype(np.float32)
     out = np.empty_like(big)
     fp = C.POINTER(C.c_float)
     L.wro_sin_many.argtypes = [fp, C.c_int, fp]
     L.wro_sin_many(big.ctypes.data_as(fp), len(big), out.ctypes.data_as(fp))
-    assert np.abs(out.astype(np.float64) - np.sin(big.astype(np.float64))).max() < 1.45e-7
+    assert np.abs(out.astype(np.float64) - np.sin(big.astype(np.float64))).max() < 1.8e-7
     assert np.abs(out).max() <= 1.0
-    for x in (0.3, 2.5, 1000.25, 123456.7, 8.0e6):
+    for x in (0.3, 2.5, 1000.25, 123456.7, 8.0e6, 9.0e8):
         assert L.wro_sin(-x) == -L.wro_sin(x)
-    # large arguments stay bounded and deterministic; from 2^23 on the rule says 0
-    assert abs(L.wro_sin(4.0e6)) <= 1.0 and L.wro_sin(8388608.0) == 0.0 and L.wro_sin(2.0e9) == 0.0 and L.wro_sin(float("inf")) == 0.0
-    assert L.wro_sin(8388607.5) != 0.0 and np.isnan(L.wro_sin(float("nan"))) == False
+    # beyond 2^24 the three-part reduction runs out of bits, as in the published algorithm: the
+    # value is finite and deterministic but no longer a sine; from 2^30 on the rule says 0
+    assert abs(L.wro_sin(4.0e6)) <= 1.0 and np.isfinite(L.wro_sin(1.0e9)) and L.wro_sin(1.0e9) != 0.0
+    assert L.wro_sin(1073741824.0) == 0.0 and L.wro_sin(2.0e9) == 0.0 and L.wro_sin(float("inf")) == 0.0
+    assert not np.isnan(L.wro_sin(float("nan")))
+
+
+def test_hash_fraction_never_rounds_up_to_one():
+    """The device takes the hash's fractional part with the hardware's fraction instruction,
+    which differs from s - floor(s) only where that rounds up to 1.0.  Every float argument
+    with 2^-20 <= |d| < 2^30 (a lattice dot product is 0 or at least 2^-20 in magnitude) is
+    tried here: no such case exists."""
+    from concurrent.futures import ThreadPoolExecutor
+    L.wro_hash_fract_exceptions.restype = C.c_uint64
+    L.wro_hash_fract_exceptions.argtypes = [C.c_uint32] * 4
+    lo, hi = bits(2.0 ** -20), bits(2.0 ** 30)
+    with ThreadPoolExecutor(8) as ex:
+        bad = sum(ex.map(lambda t: L.wro_hash_fract_exceptions(lo, hi, 8, t), range(8)))
+    assert bad == 0
+    assert L.wro_hash_fract_exceptions(bits(0.0), bits(0.0) + 1, 1, 0) == 0
 
 
 def test_rand_is_the_sin_hash():

@@ -76,43 +76,54 @@ inline void mat4_mul_mat4(const float* a, const float* b, float* out) {  // out 
     }
 }
 
-// Software sine used by the fog noise hash (noise.wgsl:4): WGSL leaves the accuracy of sin
-// to the implementation, so the restatement fixes one algorithm and both sides run it.
-//   q  = x/pi rounded to the nearest integer by adding 1.5*2^23 in a fused multiply-add
-//        (exact rounding for |q| < 2^22; the sum's lowest mantissa bit is q's parity),
-//   r  = x - q*pi, pi taken in three parts (3.140625 + 9.675e-4 + 1.51e-7) by fused
-//        multiply-adds, |r| <= pi/2 (up to 2.3 near |x| = 2^23 where q can be one off),
-//   sin(r) = r + r*z*P(z), z = r*r, P of degree 4 (odd degree-11 minimax on [0, 2.3],
-//        polynomial error 2.4e-9), Horner with fused multiply-adds,
-//   result negated for odd q through the parity bit moved to the sign position.
-// Checked against a double-precision sine on every float in [0, 2^23): largest absolute error
-// 1.41e-7 (1.25e-7 below 1e5), odd symmetry exact.  |x| >= 2^23 (where one float ulp is a
-// whole radian) or NaN -> +0.  GUARD = false is for callers that have already bounded |x| below
-// 2^23; for such x both forms return the same bits.
-constexpr float kSinRange = 8388608.0f;
+// Software sine of the fog noise hash (noise.wgsl:4).  WGSL leaves the accuracy of sin to the
+// implementation; the driver the reference is judged on (Mesa llvmpipe/lavapipe) lowers it to
+// the single-precision Cephes scheme (as in sse_mathfun's sin_ps), so that is the contract:
+//   j   = octant of |x|: trunc(|x| * 4/pi), rounded up to even,
+//   r   = |x| - j*pi/4, pi/4 taken in three parts (0.78515625 + 2.4187564849853515625e-4 +
+//         3.77489497744594108e-8) by fused multiply-adds,
+//   j&2 = 0: sin(r) = r + r*z*(s2 + z*(s1 + z*s0)), z = r*r
+//   j&2 = 2: cos(r) = 1 - z/2 + z*z*(c2 + z*(c1 + z*c0))
+//   sign = sign(x) xor (j&4).
+// |x| >= 2^30 (where trunc no longer fits the octant arithmetic) or NaN -> +0.  GUARD = false
+// is for callers that have already bounded |x| below 2^30; for such x both forms return the
+// same bits.  On the device both polynomials are evaluated and one is selected (two dependent
+// chains that fill each other's latency; a branch would diverge on every hash).
+constexpr float kSinRange = 1073741824.0f;
 template <bool GUARD>
 WR_HD float wr_sin_t(float x) {
+    float ax = fabsf(x);
+    uint32_t sign = f2u(x) & 0x80000000u;
     if (GUARD) {
         // Branch-free: an out-of-range (or NaN) argument is replaced by +0 on entry, for
         // which the arithmetic below yields +0.
-        x = fabsf(x) < kSinRange ? x : 0.0f;
+        const bool in_range = ax < kSinRange;
+        ax = in_range ? ax : 0.0f;
+        sign = in_range ? sign : 0u;
     }
-    float qm = fmaf(x, 0.318309886183790672f, 12582912.0f);
-    float q = qm - 12582912.0f;
-    float r = fmaf(q, -3.140625f, x);
-    r = fmaf(q, -9.67502593994140625e-4f, r);
-    r = fmaf(q, -1.509957990978376432e-7f, r);
-    float z = r * r;
-    float p = -2.2534795035e-08f;
-    p = fmaf(p, z, 2.7403378113e-06f);
-    p = fmaf(p, z, -1.9836860877e-04f);
-    p = fmaf(p, z, 8.3332759288e-03f);
-    p = fmaf(p, z, -1.6666664062e-01f);
-    float t = z * r;
-    float res = fmaf(p, t, r);
-    // adding the parity bit at the sign position flips the sign (the carry leaves the word):
-    // the same bits as an exclusive or, in one shift-add instruction on the device
-    return u2f(f2u(res) + (f2u(qm) << 31));
+    const float y0 = ax * 1.27323954473516f;
+    int j = (int)y0;
+    j = (j + 1) & ~1;
+    const float y = (float)j;
+    float r = fmaf(y, -0.78515625f, ax);
+    r = fmaf(y, -2.4187564849853515625e-4f, r);
+    r = fmaf(y, -3.77489497744594108e-8f, r);
+    const float z = r * r;
+    float ps = -1.9515295891e-4f;
+    ps = fmaf(ps, z, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    ps = ps * z;
+    ps = fmaf(ps, r, r);
+    float pc = 2.443315711809948e-5f;
+    pc = fmaf(pc, z, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    pc = pc * z;
+    pc = pc * z;
+    pc = fmaf(z, -0.5f, pc);
+    pc = pc + 1.0f;
+    const float res = (j & 2) ? pc : ps;
+    // bit 2 of j moved to the sign position; xor with the argument's sign
+    return u2f(f2u(res) ^ sign ^ (((uint32_t)j << 29) & 0x80000000u));
 }
 WR_HD float wr_sin(float x) { return wr_sin_t<true>(x); }
 
@@ -602,7 +613,8 @@ WR_HD V4 fs_pbr(const FrameConsts& fc, const ShadowMap& sm, const uint32_t* texe
 // where s - floor(s) rounds up to 1.0 (a negative s of less than 2^-25 in magnitude), which
 // the noise hash cannot produce: its s is sin(d) * 42123.45 for the dot product d of an
 // integer lattice point, d is 0 or at least 2^-20 in magnitude, and for every float d with
-// 2^-20 <= |d| < 2^23 the difference stays below 1 (checked exhaustively).
+// 2^-20 <= |d| < 2^30 the sine is at least 8.3e-9 in magnitude, so the difference stays below 1
+// (checked exhaustively: wro_hash_fract_exceptions in the oracle, run by the CPU tests).
 WR_HD float hash_fract(float s) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_fractf(s);
@@ -718,19 +730,17 @@ WR_HD float fbm_tab_t(V3 p, const NoiseTable* tabs) {
     return saturatef(ret);
 }
 // noise.wgsl:26-40.  The last octave samples p*128 and every hash argument is at most
-// (|q|+1) * (12.345 + 67.89 + 412.12) (1 + 3*2^-24); for |p| < 133 that stays below 2^23
-// (8382346 < 8388608), the sine's range guard can never fire and the unguarded instantiation
-// is used.
-constexpr float kFbmUnguarded = 133.0f;
+// (|q|+1) * (12.345 + 67.89 + 412.12) (1 + 3*2^-24); for |p| < 16000 that stays below 2^30,
+// the sine's range guard can never fire and the unguarded instantiation is used.  The same
+// bound keeps the float -> int conversions that index the hash tables exact
+// (|p| * 128 + 1 < 2^24).
+constexpr float kFbmUnguarded = 16000.0f;
 WR_HD float fbm(V3 p) {
     if (fabsf(p.x) < kFbmUnguarded && fabsf(p.y) < kFbmUnguarded && fabsf(p.z) < kFbmUnguarded) return fbm_t<false>(p);  // false for NaN
     return fbm_t<true>(p);
 }
-// Tables are indexed through float -> int conversions, exact while |p| * 128 + 1 < 2^24.
-constexpr float kFbmTabled = 16000.0f;
 WR_HD float fbm_tab(V3 p, const NoiseTable* tabs) {
     if (fabsf(p.x) < kFbmUnguarded && fabsf(p.y) < kFbmUnguarded && fabsf(p.z) < kFbmUnguarded) return fbm_tab_t<false>(p, tabs);
-    if (fabsf(p.x) < kFbmTabled && fabsf(p.y) < kFbmTabled && fabsf(p.z) < kFbmTabled) return fbm_tab_t<true>(p, tabs);
     return fbm_t<true>(p);
 }
 // fog.wgsl:48-62
