@@ -217,6 +217,24 @@ int wr_render_batch(WrContext* ctx, const WrCameraUniform* cameras, uint32_t cou
                     const WrLightUniform* light, const WrGlobalUniforms* globals,
                     uint32_t passes, int shadows_every_frame, void* device_frames);
 
+/* wr_render_frame for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  Renders the same frame as wr_render_frame, bit for bit, with every work buffer
+ * of the frame (shadow maps, bin lists, visibility, ordered-blend lists, fog items, noise
+ * tables) inside one file-scope device array of 96 MiB that each GPU using the library holds
+ * until the process ends; the finished RGBA8 frame goes to `device_color` (device memory,
+ * width*height*4 bytes, brought by the caller).  Calls no hipMalloc / hipFree.  The scene must
+ * already be resident: the first wr_render_frame after an upload or resize makes it so,
+ * otherwise WR_ERR_NO_SCENE.  A target and scene whose work buffers do not fit the array
+ * (roughly: beyond 320x180 pixels with 256^2 shadow faces and 16k triangles; the error text
+ * gives the exact need) return WR_ERR_CAPACITY; bin-sharded contexts return
+ * WR_ERR_UNSUPPORTED.  All calls on one GPU share that GPU's array, from any context: calls
+ * that overlap on one GPU race.  Results are complete, as seen from the context's stream,
+ * when the call's work has run (wr_sync); wr_read_* keep referring to wr_render_frame's
+ * buffers. */
+int wr_render_frame_static(WrContext* ctx, const WrCameraUniform* camera, const WrLightUniform* light,
+                           const WrGlobalUniforms* globals, uint32_t passes, void* device_color);
+
 /* Blocks until the context's stream is idle (surface_texture.present(), state.rs:806,
  * is the reference's end-of-frame point). */
 int wr_sync(WrContext* ctx);

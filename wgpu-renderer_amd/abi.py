@@ -113,6 +113,7 @@ SYMBOLS = {
     "wr_set_instances": (C.c_int, [_P, C.c_uint32, C.POINTER(InstanceRaw), C.c_uint32]),
     "wr_clear_scene": (C.c_int, [_P]),
     "wr_render_frame": (C.c_int, [_P, C.POINTER(CameraUniform), C.POINTER(LightUniform), C.POINTER(GlobalUniforms), C.c_uint32]),
+    "wr_render_frame_static": (C.c_int, [_P, C.POINTER(CameraUniform), C.POINTER(LightUniform), C.POINTER(GlobalUniforms), C.c_uint32, _P]),
     "wr_render_batch": (C.c_int, [_P, C.POINTER(CameraUniform), C.c_uint32, C.POINTER(LightUniform), C.POINTER(GlobalUniforms), C.c_uint32, C.c_int, _P]),
     "wr_sync": (C.c_int, [_P]),
     "wr_read_color": (C.c_int, [_P, _P, C.c_size_t]),
@@ -340,6 +341,11 @@ class Renderer:
     # ---- frames
     def render_frame(self, camera: CameraUniform, light: LightUniform, globals_: GlobalUniforms, passes: int):
         self._check(self.lib.wr_render_frame(self.h, C.byref(camera), C.byref(light), C.byref(globals_), passes))
+
+    def render_frame_static(self, camera, light, globals_, passes: int, device_color: int):
+        """wr_render_frame_static: the same frame without any device allocation, written to the
+        caller's device buffer (width*height*4 bytes)."""
+        self._check(self.lib.wr_render_frame_static(self.h, C.byref(camera), C.byref(light), C.byref(globals_), passes, device_color))
 
     def upload_glb(self, model: int, glb: "Glb"):
         """load_model_gltf's uploads for one model: textures, materials, meshes in draw order."""

@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -43,6 +44,17 @@ constexpr size_t kNoiseLevelEntries = 4u << 20;  // largest hash table of one no
 constexpr size_t kNoisePoolEntries = 8u << 20;    // all levels together (32 MB per frame in flight)
 static_assert(sizeof(FrameConsts) < 3072, "FrameConsts must fit the kernel argument segment");
 
+// Work buffers of wr_render_frame_static, the entry point for callers that cannot allocate.
+// One copy per device that loads the library, held until the process ends.  The name is a
+// host-side stand-in: host code reaches the memory only through g_scratch_ptr[device], taken
+// once per device with hipGetSymbolAddress in wr_create.
+constexpr size_t kStaticScratchBytes = (size_t)96 << 20;
+constexpr size_t kStaticNoisePoolEntries = (size_t)1 << 20;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+constexpr int kMaxScratchDevices = 64;
+static unsigned char* g_scratch_ptr[kMaxScratchDevices];
+static std::mutex g_scratch_mutex;
+
 namespace {
 
 struct ModelHost {
@@ -62,6 +74,27 @@ struct ModelDev {
     uint32_t nv = 0, ntris = 0;
 };
 struct TexHost { uint32_t w, h; int srgb; std::vector<uint8_t> px; };
+
+// Where a frame's work buffers come from: base == nullptr makes every block its own
+// hipMalloc (contexts created by wr_create); otherwise blocks are carved, 256-byte aligned,
+// from [base, base + cap) and nothing is allocated (wr_render_frame_static).  With
+// dry == true nothing is handed out, only `off` advances: the size a set of buffers needs.
+struct Arena {
+    uint8_t* base = nullptr;
+    size_t off = 0, cap = 0;
+    bool dry = false;
+    bool carving() const { return base != nullptr || dry; }
+};
+template <class T>
+hipError_t arena_take(Arena& a, T*& p, size_t bytes) {
+    if (!a.carving()) return hipMalloc(&p, bytes);
+    const size_t o = (a.off + 255) & ~(size_t)255;
+    a.off = o + bytes;
+    if (a.dry) { p = nullptr; return hipSuccess; }
+    if (a.off > a.cap) return hipErrorOutOfMemory;
+    p = reinterpret_cast<T*>(a.base + o);
+    return hipSuccess;
+}
 
 struct WsAlloc {
     RasterWS ws{};
@@ -91,6 +124,7 @@ struct FrameRes {
     BlendWS blend{};                 // ordered-blend work space, sized with the colour target
     size_t blend_clear_bytes = 0;    // counts + bin flags, cleared every frame
     float* d_noise_pool = nullptr;   // hash tables of the low noise octaves, rebuilt every frame
+    size_t noise_pool_entries = 0;   // capacity of d_noise_pool
     uint32_t* d_fog_pixel = nullptr; // [W*H] fog march work items: pixel index
     float4* d_fog_ray = nullptr;     // [W*H] ray origin + max_fog_depth
     float4* d_fog_src = nullptr;     // [W*H] marched fog colour of each item
@@ -107,6 +141,7 @@ struct WrContext {
     ModelHost host[3];
     std::vector<TexHost> tex_host;
     bool scene_dirty = true;
+    bool broken = false;  // a resize ran out of memory: the targets are gone, nothing can be rendered
 
     ModelDev dev[3];
     MatDesc* d_mats = nullptr;
@@ -159,27 +194,34 @@ void free_ws(WsAlloc& w) {
     w = WsAlloc();
 }
 
-int alloc_ws(WrContext* ctx, WsAlloc& w, uint32_t slots, uint32_t ovf_cap, uint32_t items_cap, int bins_x, int bins_y,
+int alloc_ws(WrContext* ctx, Arena& ar, WsAlloc& w, uint32_t slots, uint32_t ovf_cap, uint32_t items_cap, int bins_x, int bins_y,
              int layers, uint32_t* err, uint32_t* total_items, size_t extra_counters = 0) {
-    free_ws(w);
+    if (!ar.carving()) free_ws(w);
     RasterWS& ws = w.ws;
     ws.slots = slots; ws.ovf_cap = ovf_cap; ws.items_cap = items_cap;
     ws.bins_x = bins_x; ws.bins_y = bins_y; ws.layers = layers;
     ws.err = err; ws.total_items = total_items;
     size_t nb = (size_t)bins_x * bins_y * layers;
-    WR_HIP(hipMalloc(&ws.recs, sizeof(Rec) * (size_t)layers * ((size_t)slots + ovf_cap)));
-    WR_HIP(hipMalloc(&ws.bb, sizeof(uint2) * (size_t)layers * ((size_t)slots + ovf_cap)));
-    WR_HIP(hipMalloc(&ws.betas, sizeof(float) * 9 * (size_t)layers * ovf_cap + 64));
+    WR_HIP(arena_take(ar, ws.recs, sizeof(Rec) * (size_t)layers * ((size_t)slots + ovf_cap)));
+    WR_HIP(arena_take(ar, ws.bb, sizeof(uint2) * (size_t)layers * ((size_t)slots + ovf_cap)));
+    WR_HIP(arena_take(ar, ws.betas, sizeof(float) * 9 * (size_t)layers * ovf_cap + 64));
     w.counters_bytes = sizeof(uint32_t) * (2 * (size_t)layers + 2 * nb + extra_counters);
-    WR_HIP(hipMalloc(&w.counters, w.counters_bytes));
+    WR_HIP(arena_take(ar, w.counters, w.counters_bytes));
+    if (ar.dry) {  // sizing pass: no pointers to derive
+        size_t dummy_bytes[3] = {sizeof(uint32_t) * (size_t)layers * slots, sizeof(uint32_t) * (nb + 1), sizeof(uint32_t) * ((size_t)items_cap + 1)};
+        void* dummy = nullptr;
+        for (size_t b : dummy_bytes) WR_HIP(arena_take(ar, dummy, b));
+        return WR_OK;
+    }
     ws.ovf_count = w.counters;
     ws.bin_count = w.counters + layers;
     ws.bin_cursor = ws.bin_count + nb;
     ws.clip_count = ws.bin_cursor + nb;
-    WR_HIP(hipMalloc(&ws.clip_queue, sizeof(uint32_t) * (size_t)layers * slots));
-    WR_HIP(hipMalloc(&ws.bin_offset, sizeof(uint32_t) * (nb + 1)));
-    WR_HIP(hipMalloc(&ws.bin_items, sizeof(uint32_t) * ((size_t)items_cap + 1)));
-    WR_HIP(hipMemset(w.counters, 0, w.counters_bytes));
+    WR_HIP(arena_take(ar, ws.clip_queue, sizeof(uint32_t) * (size_t)layers * slots));
+    WR_HIP(arena_take(ar, ws.bin_offset, sizeof(uint32_t) * (nb + 1)));
+    WR_HIP(arena_take(ar, ws.bin_items, sizeof(uint32_t) * ((size_t)items_cap + 1)));
+    // (the counters are cleared at the start of every frame that uses them)
+    if (!ar.carving()) WR_HIP(hipMemset(w.counters, 0, w.counters_bytes));
     return WR_OK;
 }
 
@@ -206,36 +248,46 @@ void free_scene(WrContext* c) {
     }
 }
 
+// The buffers of one frame in flight that depend on the target size.  `color` == false leaves
+// d_color alone (the caller of wr_render_frame_static brings the colour target).
+int alloc_frame_targets(WrContext* ctx, Arena& ar, FrameRes* f, bool color) {
+    const size_t n = (size_t)ctx->W * ctx->H;
+    WR_HIP(arena_take(ar, f->d_vis, n * 4));
+    WR_HIP(arena_take(ar, f->d_depth, n * 4));
+    if (color) WR_HIP(arena_take(ar, f->d_color, n * 4));
+    // Ordered blending: every pixel can be flagged, and every flagged pixel keeps up to
+    // kReplayK covering fragments (128 bytes per pixel of the target; only flagged pixels'
+    // lists are ever touched).
+    BlendWS& b = f->blend;
+    const size_t nbins = (size_t)((ctx->W + kBin - 1) / kBin) * (size_t)((ctx->H + kBin - 1) / kBin);
+    b.cap = (uint32_t)n; b.frag_cap = (uint32_t)n;
+    f->blend_clear_bytes = sizeof(uint32_t) * (4 + nbins);
+    WR_HIP(arena_take(ar, b.rp_slot, n * 4));
+    WR_HIP(arena_take(ar, b.slot_pixel, n * 4));
+    WR_HIP(arena_take(ar, b.counts, f->blend_clear_bytes));
+    b.bin_flag = b.counts ? b.counts + 4 : nullptr;
+    WR_HIP(arena_take(ar, b.lists, n * kReplayK * sizeof(uint2)));
+    WR_HIP(arena_take(ar, b.list_count, n * 4));
+    WR_HIP(arena_take(ar, b.slow_slots, n * 4));
+    WR_HIP(arena_take(ar, b.slot_frags, n * sizeof(uint2)));
+    WR_HIP(arena_take(ar, b.frag_item, n * sizeof(uint2)));
+    WR_HIP(arena_take(ar, b.frag_src, n * sizeof(float4)));
+    WR_HIP(arena_take(ar, f->d_fog_pixel, n * 4));
+    WR_HIP(arena_take(ar, f->d_fog_ray, n * sizeof(float4)));
+    WR_HIP(arena_take(ar, f->d_fog_src, n * sizeof(float4)));
+    WR_HIP(arena_take(ar, f->d_fog_multi, n * 4));
+    return WR_OK;
+}
+
 int alloc_targets(WrContext* ctx) {
     free_targets(ctx);
-    size_t n = (size_t)ctx->W * ctx->H;
+    const size_t n = (size_t)ctx->W * ctx->H;
     for (int k = 0; k < ctx->nfr; ++k) {
         FrameRes* f = &ctx->fr[k];
-        WR_HIP(hipMalloc(&f->d_vis, n * 4));
-        WR_HIP(hipMalloc(&f->d_depth, n * 4));
-        WR_HIP(hipMalloc(&f->d_color, n * 4));
-        // Ordered blending: every pixel can be flagged, and every flagged pixel keeps up to
-        // kReplayK covering fragments (128 bytes per pixel of the target; only flagged pixels'
-        // lists are ever touched).
-        BlendWS& b = f->blend;
-        const size_t nbins = (size_t)((ctx->W + kBin - 1) / kBin) * (size_t)((ctx->H + kBin - 1) / kBin);
-        b.cap = (uint32_t)n; b.frag_cap = (uint32_t)n;
-        f->blend_clear_bytes = sizeof(uint32_t) * (4 + nbins);
-        WR_HIP(hipMalloc(&b.rp_slot, n * 4));
-        WR_HIP(hipMalloc(&b.slot_pixel, n * 4));
-        WR_HIP(hipMalloc(&b.counts, f->blend_clear_bytes));
-        b.bin_flag = b.counts + 4;
-        WR_HIP(hipMalloc(&b.lists, n * kReplayK * sizeof(uint2)));
-        WR_HIP(hipMalloc(&b.list_count, n * 4));
-        WR_HIP(hipMalloc(&b.slow_slots, n * 4));
-        WR_HIP(hipMalloc(&b.slot_frags, n * sizeof(uint2)));
-        WR_HIP(hipMalloc(&b.frag_item, n * sizeof(uint2)));
-        WR_HIP(hipMalloc(&b.frag_src, n * sizeof(float4)));
-        WR_HIP(hipMemset(b.rp_slot, 0, n * 4));
-        WR_HIP(hipMalloc(&f->d_fog_pixel, n * 4));
-        WR_HIP(hipMalloc(&f->d_fog_ray, n * sizeof(float4)));
-        WR_HIP(hipMalloc(&f->d_fog_src, n * sizeof(float4)));
-        WR_HIP(hipMalloc(&f->d_fog_multi, n * 4));
+        Arena ar;
+        int rc = alloc_frame_targets(ctx, ar, f, true);
+        if (rc != WR_OK) return rc;
+        WR_HIP(hipMemset(f->blend.rp_slot, 0, n * 4));
         WR_HIP(hipMemset(f->d_color, 0, n * 4));
     }
     return WR_OK;
@@ -248,6 +300,43 @@ int sync_all(WrContext* ctx) {
         if (ctx->fr[k].side) WR_HIP(hipStreamSynchronize(ctx->fr[k].side));
     }
     WR_HIP(hipStreamSynchronize(ctx->stream));
+    return WR_OK;
+}
+
+// The buffers of one frame in flight that depend on the uploaded scene: vertex-stage outputs
+// and the three raster work spaces.
+int alloc_frame_scene(WrContext* ctx, Arena& ar, FrameRes* f) {
+    const uint32_t nvg = ctx->dev[WR_MODEL_GEOMETRY].nv, ntg = ctx->dev[WR_MODEL_GEOMETRY].ntris;
+    const uint32_t ntl = ctx->dev[WR_MODEL_LIGHT_MARKER].ntris, ntf = ctx->dev[WR_MODEL_FOG_VOLUME].ntris;
+    const size_t nvs = std::max<uint32_t>(nvg, 1);
+    WR_HIP(arena_take(ar, f->vout.clip, sizeof(float4) * nvs));
+    WR_HIP(arena_take(ar, f->vout.v0, sizeof(float4) * nvs));
+    WR_HIP(arena_take(ar, f->vout.v1, sizeof(float4) * nvs));
+    WR_HIP(arena_take(ar, f->vout.v2, sizeof(float4) * nvs));
+    WR_HIP(arena_take(ar, f->vout.v3, sizeof(float4) * nvs));
+    WR_HIP(arena_take(ar, f->d_shadow_clip, sizeof(float4) * nvs * 6));
+    int rc;
+    // capacities in 64 bits: the sums pass 2^32 for meshes well below the 2^29-triangle limit
+    {
+        const uint64_t slots = (uint64_t)ntg + ntl;
+        const uint64_t ovf = slots / 2 + 8192;
+        const int bx = (ctx->W + kBin - 1) / kBin, by = (ctx->H + kBin - 1) / kBin;
+        const uint64_t items = 8u * (slots + ovf) + 64u * (uint64_t)(bx * by) + (1u << 20);
+        if (slots + ovf > 0xFFFFFFF0ull || items > 0xFFFFFFF0ull) return fail(ctx, WR_ERR_UNSUPPORTED, "geometry too large for the 32-bit bin lists");
+        if ((rc = alloc_ws(ctx, ar, f->geom, (uint32_t)std::max<uint64_t>(slots, 1), (uint32_t)ovf, (uint32_t)items, bx, by, 1, ctx->d_err, ctx->d_err + 1)) != WR_OK) return rc;
+    }
+    {
+        const uint64_t slots = std::max(ntg, 1u);
+        const uint64_t ovf = slots / 4 + 8192;
+        const int bs = (ctx->S + kBin - 1) / kBin;
+        const uint64_t items = 6u * (4u * slots + 64u * (uint64_t)(bs * bs) + (1u << 18));
+        if (6 * (slots + ovf) > 0xFFFFFFF0ull || items > 0xFFFFFFF0ull) return fail(ctx, WR_ERR_UNSUPPORTED, "geometry too large for the 32-bit bin lists");
+        if ((rc = alloc_ws(ctx, ar, f->shadow, (uint32_t)slots, (uint32_t)ovf, (uint32_t)items, bs, bs, 6, ctx->d_err, ctx->d_err + 2)) != WR_OK) return rc;
+    }
+    {
+        const uint32_t slots = std::max(ntf, 1u);
+        if ((rc = alloc_ws(ctx, ar, f->fog, slots, slots * kMaxFan + 8, 8, 1, 1, 1, ctx->d_err, ctx->d_err + 3)) != WR_OK) return rc;
+    }
     return WR_OK;
 }
 
@@ -331,37 +420,12 @@ int build_scene(WrContext* ctx) {
         WR_HIP(hipMalloc(&ctx->d_mats, std::max<size_t>(mats.size(), 1) * sizeof(MatDesc)));
         if (!mats.empty()) WR_HIP(hipMemcpy(ctx->d_mats, mats.data(), mats.size() * sizeof(MatDesc), hipMemcpyHostToDevice));
     }
-    const uint32_t nvg = ctx->dev[WR_MODEL_GEOMETRY].nv, ntg = ctx->dev[WR_MODEL_GEOMETRY].ntris;
-    const uint32_t ntl = ctx->dev[WR_MODEL_LIGHT_MARKER].ntris, ntf = ctx->dev[WR_MODEL_FOG_VOLUME].ntris;
+    const uint32_t ntg = ctx->dev[WR_MODEL_GEOMETRY].ntris, ntl = ctx->dev[WR_MODEL_LIGHT_MARKER].ntris;
     if ((uint64_t)ntg + ntl >= (1u << 29)) return fail(ctx, WR_ERR_UNSUPPORTED, "more than 2^29 triangles");
-    size_t nvs = std::max<uint32_t>(nvg, 1);
     for (int k = 0; k < ctx->nfr; ++k) {
-        FrameRes* f = &ctx->fr[k];
-        WR_HIP(hipMalloc(&f->vout.clip, sizeof(float4) * nvs));
-        WR_HIP(hipMalloc(&f->vout.v0, sizeof(float4) * nvs));
-        WR_HIP(hipMalloc(&f->vout.v1, sizeof(float4) * nvs));
-        WR_HIP(hipMalloc(&f->vout.v2, sizeof(float4) * nvs));
-        WR_HIP(hipMalloc(&f->vout.v3, sizeof(float4) * nvs));
-        WR_HIP(hipMalloc(&f->d_shadow_clip, sizeof(float4) * nvs * 6));
-        int rc;
-        {
-            uint32_t slots = ntg + ntl;
-            uint32_t ovf = slots / 2 + 8192;
-            int bx = (ctx->W + kBin - 1) / kBin, by = (ctx->H + kBin - 1) / kBin;
-            uint32_t items = 8u * (slots + ovf) + 64u * (uint32_t)(bx * by) + (1u << 20);
-            if ((rc = alloc_ws(ctx, f->geom, std::max(slots, 1u), ovf, items, bx, by, 1, ctx->d_err, ctx->d_err + 1)) != WR_OK) return rc;
-        }
-        {
-            uint32_t slots = std::max(ntg, 1u);
-            uint32_t ovf = slots / 4 + 8192;
-            int bs = (ctx->S + kBin - 1) / kBin;
-            uint32_t items = 6u * (4u * slots + 64u * (uint32_t)(bs * bs) + (1u << 18));
-            if ((rc = alloc_ws(ctx, f->shadow, slots, ovf, items, bs, bs, 6, ctx->d_err, ctx->d_err + 2)) != WR_OK) return rc;
-        }
-        {
-            uint32_t slots = std::max(ntf, 1u);
-            if ((rc = alloc_ws(ctx, f->fog, slots, slots * kMaxFan + 8, 8, 1, 1, 1, ctx->d_err, ctx->d_err + 3)) != WR_OK) return rc;
-        }
+        Arena ar;
+        int rc = alloc_frame_scene(ctx, ar, &ctx->fr[k]);
+        if (rc != WR_OK) return rc;
     }
     ctx->scene_dirty = false;
     return WR_OK;
@@ -542,7 +606,7 @@ NoiseTables plan_noise_tables(const WrContext* ctx, const FrameRes* f, const Fra
                 n[r] = (long)std::floor(b) + 2 - l[r] + 1;
             }
             double entries = (double)n[0] * n[1] * n[2];
-            if (entries > (double)kNoiseLevelEntries || used + (size_t)entries > kNoisePoolEntries) continue;
+            if (entries > (double)std::min(kNoiseLevelEntries, f->noise_pool_entries) || used + (size_t)entries > f->noise_pool_entries) continue;
             NoiseTable& t = nt.level[k * 8 + o];
             t.data = f->d_noise_pool + used;
             t.lox = (int)l[0]; t.loy = (int)l[1]; t.loz = (int)l[2];
@@ -709,6 +773,7 @@ FrameRes* next_frame(WrContext* ctx) {
 
 int check_ready(WrContext* ctx, uint32_t passes) {
     if (!ctx) return WR_ERR_INVALID_ARGUMENT;
+    if (ctx->broken) return fail(ctx, WR_ERR_OUT_OF_MEMORY, "the last wr_resize failed: resize again before rendering");
     if (ctx->host[WR_MODEL_GEOMETRY].idx.empty() || !ctx->host[WR_MODEL_GEOMETRY].has_inst)
         return fail(ctx, WR_ERR_NO_SCENE, "geometry model needs at least one mesh and an instance");
     if (ctx->host[WR_MODEL_GEOMETRY].mats.empty())
@@ -738,6 +803,15 @@ int wr_create(const WrConfig* config, WrContext** out_ctx) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return WR_ERR_DEVICE;
     if (config->device < 0 || config->device >= ndev) return WR_ERR_INVALID_ARGUMENT;
     if (hipSetDevice(config->device) != hipSuccess) return WR_ERR_DEVICE;
+    if (config->device < kMaxScratchDevices) {
+        // this device's copy of the static work buffer (every device has its own, at its own address)
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[config->device]) {
+            void* p = nullptr;
+            if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return WR_ERR_DEVICE;
+            g_scratch_ptr[config->device] = static_cast<unsigned char*>(p);
+        }
+    }
     WrContext* ctx = new WrContext();
     ctx->cfg = *config;
     ctx->W = (int)config->width; ctx->H = (int)config->height; ctx->S = (int)S;
@@ -767,6 +841,7 @@ int wr_create(const WrConfig* config, WrContext** out_ctx) {
         for (int k = 0; k < ctx->nfr; ++k) {
             FrameRes* f = &ctx->fr[k];
             WR_HIP(hipMalloc(&f->d_noise_pool, kNoisePoolEntries * sizeof(float)));
+            f->noise_pool_entries = kNoisePoolEntries;
             WR_HIP(hipMalloc(&f->d_shadow, ns * 4));
             hipLaunchKernelGGL(k_fill_f32, dim3((uint32_t)((ns + 255) / 256)), dim3(256), 0, ctx->stream, f->d_shadow, ns, 1.0f);
         }
@@ -815,7 +890,10 @@ int wr_resize(WrContext* ctx, uint32_t width, uint32_t height) {
     ctx->W = (int)width; ctx->H = (int)height;
     ctx->cfg.width = width; ctx->cfg.height = height;
     ctx->scene_dirty = true;
-    return alloc_targets(ctx);
+    const int rc = alloc_targets(ctx);
+    ctx->broken = rc != WR_OK;
+    if (ctx->broken) free_targets(ctx);
+    return rc;
 }
 
 const char* wr_last_error(const WrContext* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -889,6 +967,63 @@ int wr_render_frame(WrContext* ctx, const WrCameraUniform* camera, const WrLight
     FrameRes* f = next_frame(ctx);
     if ((rc = frame_stages(ctx, f, fc, passes, true)) != WR_OK) return rc;
     return finish_frame(ctx, f);
+}
+
+// The work buffers of one frame, carved from `ar` (no allocation): shadow maps, noise tables,
+// target-sized and scene-sized buffers.  The colour target is the caller's.
+static int carve_static_frame(WrContext* ctx, Arena& ar, FrameRes* f) {
+    WR_HIP(arena_take(ar, f->d_shadow, (size_t)6 * ctx->S * ctx->S * 4));
+    WR_HIP(arena_take(ar, f->d_noise_pool, kStaticNoisePoolEntries * sizeof(float)));
+    f->noise_pool_entries = kStaticNoisePoolEntries;
+    int rc = alloc_frame_targets(ctx, ar, f, false);
+    if (rc != WR_OK) return rc;
+    return alloc_frame_scene(ctx, ar, f);
+}
+
+int wr_render_frame_static(WrContext* ctx, const WrCameraUniform* camera, const WrLightUniform* light,
+                           const WrGlobalUniforms* globals, uint32_t passes, void* device_color) {
+    if (!ctx || !camera || !light || !globals || !device_color) return fail(ctx, WR_ERR_INVALID_ARGUMENT, "null argument");
+    if (ctx->scene_dirty)
+        return fail(ctx, WR_ERR_NO_SCENE, "the scene is not resident on the device yet: the first wr_render_frame after an upload "
+                                          "or a resize makes it so (that call allocates, this one never does)");
+    int rc = check_ready(ctx, passes);
+    if (rc != WR_OK) return rc;
+    if (ctx->cfg.tile_world > 1) return fail(ctx, WR_ERR_UNSUPPORTED, "wr_render_frame_static renders whole frames only");
+    if (ctx->cfg.device >= kMaxScratchDevices || !g_scratch_ptr[ctx->cfg.device])
+        return fail(ctx, WR_ERR_UNSUPPORTED, "no static work buffer on this device");
+    FrameRes sf;
+    const FrameRes& own = ctx->fr[0];  // streams and events exist since wr_create
+    sf.ms = own.ms; sf.side = own.side;
+    sf.ev_fork = own.ev_fork; sf.ev_start = own.ev_start; sf.ev_join = own.ev_join;
+    sf.ev_shadow_done = own.ev_shadow_done; sf.ev_geom_done = own.ev_geom_done; sf.ev_done = own.ev_done;
+    Arena sizing;
+    sizing.dry = true;
+    if ((rc = carve_static_frame(ctx, sizing, &sf)) != WR_OK) return rc;
+    if (sizing.off > kStaticScratchBytes) {
+        char msg[256];
+        snprintf(msg, sizeof(msg), "this target and scene need %zu bytes of work buffers; the static buffer of wr_render_frame_static holds %zu",
+                 sizing.off, kStaticScratchBytes);
+        return fail(ctx, WR_ERR_CAPACITY, msg);
+    }
+    Arena ar;
+    ar.base = g_scratch_ptr[ctx->cfg.device];
+    ar.cap = kStaticScratchBytes;
+    if ((rc = carve_static_frame(ctx, ar, &sf)) != WR_OK) return rc;
+    sf.d_color = static_cast<uint32_t*>(device_color);
+    // The buffer keeps what the last call left: clear what a frame reads before writing it.
+    const size_t npx = (size_t)ctx->W * ctx->H;
+    WR_HIP(hipMemsetAsync(sf.blend.rp_slot, 0, npx * 4, ctx->stream));
+    if (!(passes & WR_PASS_SHADOWS)) {
+        const size_t ns = (size_t)6 * ctx->S * ctx->S;
+        hipLaunchKernelGGL(k_fill_f32, dim3((uint32_t)((ns + 255) / 256)), dim3(256), 0, ctx->stream, sf.d_shadow, ns, 1.0f);
+    }
+    if (ctx->counting) WR_HIP(hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    FrameConsts fc = make_consts(ctx, camera, light, globals);
+    if ((rc = frame_stages(ctx, &sf, fc, passes, true)) != WR_OK) return rc;
+    WR_HIP(hipEventRecord(sf.ev_done, sf.ms));
+    ctx->fr[0].submitted = true;
+    WR_HIP(hipStreamWaitEvent(ctx->stream, sf.ev_done, 0));
+    return WR_OK;
 }
 
 int wr_render_batch(WrContext* ctx, const WrCameraUniform* cameras, uint32_t count, const WrLightUniform* light,
