@@ -144,18 +144,22 @@ typedef struct WrFrameStats {
     float ms_shadow;   /* shadow vertex + setup + binning + raster, six faces */
     float ms_geometry; /* geometry vertex + setup + binning + raster */
     float ms_shade;    /* deferred PBS shading incl. PCF and ordered blending */
-    float ms_fog;      /* fog volume raster + march */
+    float ms_fog;      /* fog volume raster + marches, incl. any wait for the shadow maps */
     float ms_total;
     uint32_t profiled_frames;    /* frames the averages above cover */
     uint32_t geometry_bin_items; /* (triangle, 64x64 bin) pairs the geometry rasteriser processed */
     uint32_t shadow_bin_items;   /* same for the six shadow faces together */
     uint64_t fog_fragments;      /* fog fragments that passed the depth test (counting mode only) */
-    uint64_t fog_noise_evals;    /* fog_noise evaluations executed (counting mode only) */
+    uint64_t fog_noise_evals;    /* fog_noise evaluations the marches of fog.wgsl execute (counting mode only) */
     uint64_t shaded_fragments;   /* PBS fragments shaded (counting mode only) */
     uint64_t replay_pixels;      /* pixels that took the ordered-blend path (counting mode only) */
     uint64_t replay_slow_pixels; /* of those, pixels covered by too many fragments for the fast path */
-    float ms_fog_march;          /* the fog march kernel alone (part of ms_fog) */
-    uint32_t reserved;
+    float ms_fog_march;          /* k_fog_noise_view alone: the noise of the view-march steps (part of ms_fog) */
+    float ms_fog_light_march;    /* k_fog_noise_light alone: the noise of the light-march steps (part of ms_fog) */
+    /* fog_noise evaluations the two noise kernels made (counting mode only): those of
+     * fog_noise_evals plus the steps a march's density exit skipped (evaluated, never read) */
+    uint64_t fog_noise_evals_view;
+    uint64_t fog_noise_evals_light;
 } WrFrameStats;
 
 /* ------------------------------------------------------------------ context */

@@ -93,7 +93,9 @@ class FrameStats(C.Structure):
         ("replay_pixels", C.c_uint64),
         ("replay_slow_pixels", C.c_uint64),
         ("ms_fog_march", C.c_float),
-        ("reserved", C.c_uint32),
+        ("ms_fog_light_march", C.c_float),
+        ("fog_noise_evals_view", C.c_uint64),
+        ("fog_noise_evals_light", C.c_uint64),
     ]
 
 

@@ -108,9 +108,9 @@ struct WsAlloc {
 // through the sets (each with its own pair of streams), so the early, latency-bound stages of
 // one frame run under the fog march of the frames before it.
 struct FrameRes {
-    // ms: geometry pass, shading, fog blend.  ss: shadow pass, then (once the geometry depth
-    // exists) the fog pass up to and including the march, next to the shading kernels.
-    hipStream_t ms = nullptr, side = nullptr;
+    // ms: geometry pass, shading, fog blend.  side: shadow pass.  fs: fog volume set-up and noise
+    // tables, then (once the geometry depth exists) the marches, next to the shading kernels.
+    hipStream_t ms = nullptr, side = nullptr, fs = nullptr;
     hipEvent_t ev_fork = nullptr, ev_start = nullptr, ev_join = nullptr, ev_shadow_done = nullptr, ev_geom_done = nullptr, ev_done = nullptr;
     bool submitted = false;  // ev_done has been recorded
 
@@ -127,7 +127,10 @@ struct FrameRes {
     size_t noise_pool_entries = 0;   // capacity of d_noise_pool
     uint32_t* d_fog_pixel = nullptr; // [W*H] fog march work items: pixel index
     float4* d_fog_ray = nullptr;     // [W*H] ray origin + max_fog_depth
-    float4* d_fog_src = nullptr;     // [W*H] marched fog colour of each item
+    float4* d_fog_res = nullptr;     // [W*H] view march result of each item
+    float* d_fog_noise_view = nullptr;   // [kFogMaxSteps][W*H] fog_noise of the view-march steps
+    float* d_fog_noise_light = nullptr;  // [kFogLightMaxSteps][W*H] fog_noise of the light-march steps
+    uint32_t* d_fog_lit = nullptr;   // [W*H] items whose fog point is lit
     uint32_t* d_fog_multi = nullptr; // [W*H] pixels with several fog fragments
 };
 
@@ -161,7 +164,7 @@ struct WrContext {
     // Profiling keeps one set of stage-boundary events per frame in a ring; wr_get_stats
     // averages the stage times over the frames recorded since profiling was switched on.
     static constexpr int kEvFrames = 128;
-    static constexpr int kEvPerFrame = 9;  // see frame_stages
+    static constexpr int kEvPerFrame = 11;  // see frame_stages
     hipEvent_t ev[kEvFrames][kEvPerFrame] = {};
     int ev_count = 0;  // frames recorded since wr_set_profiling(1), saturates at kEvFrames
     int ev_next = 0;
@@ -227,7 +230,7 @@ int alloc_ws(WrContext* ctx, Arena& ar, WsAlloc& w, uint32_t slots, uint32_t ovf
 
 void free_targets(WrContext* c) {
     for (FrameRes& f : c->fr) {
-        dfree(f.d_vis); dfree(f.d_depth); dfree(f.d_color); dfree(f.d_fog_pixel); dfree(f.d_fog_ray); dfree(f.d_fog_src); dfree(f.d_fog_multi);
+        dfree(f.d_vis); dfree(f.d_depth); dfree(f.d_color); dfree(f.d_fog_pixel); dfree(f.d_fog_ray); dfree(f.d_fog_res); dfree(f.d_fog_noise_view); dfree(f.d_fog_noise_light); dfree(f.d_fog_lit); dfree(f.d_fog_multi);
         BlendWS& b = f.blend;
         dfree(b.rp_slot); dfree(b.slot_pixel); dfree(b.counts); dfree(b.lists); dfree(b.list_count);
         dfree(b.slow_slots); dfree(b.slot_frags); dfree(b.frag_item); dfree(b.frag_src);
@@ -274,7 +277,10 @@ int alloc_frame_targets(WrContext* ctx, Arena& ar, FrameRes* f, bool color) {
     WR_HIP(arena_take(ar, b.frag_src, n * sizeof(float4)));
     WR_HIP(arena_take(ar, f->d_fog_pixel, n * 4));
     WR_HIP(arena_take(ar, f->d_fog_ray, n * sizeof(float4)));
-    WR_HIP(arena_take(ar, f->d_fog_src, n * sizeof(float4)));
+    WR_HIP(arena_take(ar, f->d_fog_res, n * sizeof(float4)));
+    WR_HIP(arena_take(ar, f->d_fog_noise_view, n * sizeof(float) * kFogMaxSteps));
+    WR_HIP(arena_take(ar, f->d_fog_noise_light, n * sizeof(float) * kFogLightMaxSteps));
+    WR_HIP(arena_take(ar, f->d_fog_lit, n * 4));
     WR_HIP(arena_take(ar, f->d_fog_multi, n * 4));
     return WR_OK;
 }
@@ -298,6 +304,7 @@ int sync_all(WrContext* ctx) {
     for (int k = 0; k < ctx->nfr; ++k) {
         if (ctx->fr[k].ms) WR_HIP(hipStreamSynchronize(ctx->fr[k].ms));
         if (ctx->fr[k].side) WR_HIP(hipStreamSynchronize(ctx->fr[k].side));
+        if (ctx->fr[k].fs) WR_HIP(hipStreamSynchronize(ctx->fr[k].fs));
     }
     WR_HIP(hipStreamSynchronize(ctx->stream));
     return WR_OK;
@@ -335,7 +342,7 @@ int alloc_frame_scene(WrContext* ctx, Arena& ar, FrameRes* f) {
     }
     {
         const uint32_t slots = std::max(ntf, 1u);
-        if ((rc = alloc_ws(ctx, ar, f->fog, slots, slots * kMaxFan + 8, 8, 1, 1, 1, ctx->d_err, ctx->d_err + 3)) != WR_OK) return rc;
+        if ((rc = alloc_ws(ctx, ar, f->fog, slots, slots * kMaxFan + 8, 8, 1, 1, 1, ctx->d_err, ctx->d_err + 3, 4)) != WR_OK) return rc;
     }
     return WR_OK;
 }
@@ -617,19 +624,23 @@ NoiseTables plan_noise_tables(const WrContext* ctx, const FrameRes* f, const Fra
     return nt;
 }
 
-// One frame.  Main stream: geometry pass, shading, fog blend.  Side stream: shadow pass, then
-// (once the geometry depth exists) the fog pass up to and including the march, which reads
-// depth and shadow maps but not the colour, next to the shading kernels.
+// One frame on three streams.  Main: geometry pass, shading (after the shadow maps), fog blend.
+// Side: the six shadow passes.  Fog: fog volume set-up and noise tables (they need the frame
+// constants only), then, once the geometry depth exists, the view march (depth and tables, no
+// shadow maps), and after the shadow maps the fog points' shadow lookups and the light march.
+// So the dominant kernel starts as soon as the geometry raster is done and runs next to the
+// shadow passes and the shading kernels.
 // Profiling events of a frame: [0] frame start, [3] geometry end, [4] shade end, [7] frame end
-// on the main stream; [1] shadow start, [2] shadow end, [8] fog start, [6] march start,
-// [5] march end on the side stream.
+// on the main stream; [1] shadow start, [2] shadow end on the side stream; [8] fog start,
+// [6] view-march noise start, [9] its end, [10] light-march noise start, [5] its end on the fog
+// stream.
 int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t passes, bool do_shadow) {
     const ModelDev& g = ctx->dev[WR_MODEL_GEOMETRY];
     const ModelDev& lm = ctx->dev[WR_MODEL_LIGHT_MARKER];
     const ModelDev& fm = ctx->dev[WR_MODEL_FOG_VOLUME];
     const bool prof = ctx->profiling;
     hipEvent_t* ev = ctx->ev[ctx->ev_next];
-    hipStream_t ms = f->ms, ss = f->side;
+    hipStream_t ms = f->ms, ss = f->side, fs = f->fs;
     int rc;
     // order the frame after what the caller has queued on its stream so far
     WR_HIP(hipEventRecord(f->ev_fork, ctx->stream));
@@ -637,14 +648,10 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
     if (prof) WR_HIP(hipEventRecord(ev[0], ms));
     const bool fog_pass = (passes & WR_PASS_FOG) && fm.ntris;
 
-    // side stream: shadow maps
-    WR_HIP(hipEventRecord(f->ev_start, ms));  // after this set's previous frame and the caller's earlier work
+    // after this set's previous frame and the caller's earlier work
+    WR_HIP(hipEventRecord(f->ev_start, ms));
     WR_HIP(hipStreamWaitEvent(ss, f->ev_start, 0));
-    if (prof) WR_HIP(hipEventRecord(ev[1], ss));
-    if (do_shadow && (passes & WR_PASS_SHADOWS))
-        if ((rc = shadow_stage(ctx, f, ss, fc)) != WR_OK) return rc;
-    if (prof) WR_HIP(hipEventRecord(ev[2], ss));
-    WR_HIP(hipEventRecord(f->ev_shadow_done, ss));
+    WR_HIP(hipStreamWaitEvent(fs, f->ev_start, 0));
 
     // main stream: geometry + light marker -> visibility / depth
     {
@@ -666,15 +673,21 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
     if (prof) WR_HIP(hipEventRecord(ev[3], ms));
     WR_HIP(hipEventRecord(f->ev_geom_done, ms));
 
-    // side stream: fog volume set-up and noise tables (they need the frame constants only),
-    // then, once the geometry depth exists, fog raster and march
+    // side stream: shadow maps
+    if (prof) WR_HIP(hipEventRecord(ev[1], ss));
+    if (do_shadow && (passes & WR_PASS_SHADOWS))
+        if ((rc = shadow_stage(ctx, f, ss, fc)) != WR_OK) return rc;
+    if (prof) WR_HIP(hipEventRecord(ev[2], ss));
+    WR_HIP(hipEventRecord(f->ev_shadow_done, ss));
+
+    // fog stream
     FogArgs fa;
     memset(&fa, 0, sizeof(fa));
     if (fog_pass) {
         ClearList cl{};
         cl.ptr[0] = f->fog.counters; cl.words[0] = (uint32_t)(f->fog.counters_bytes / 4);
-        hipLaunchKernelGGL(k_clear_words, dim3(8), dim3(256), 0, ss, cl);
-        hipLaunchKernelGGL(k_setup_small, grid1(fm.ntris), dim3(256), 0, ss, fm.pos, fm.idx, fm.ntris, 1, 1, 0u, f->fog.ws, fc);
+        hipLaunchKernelGGL(k_clear_words, dim3(8), dim3(256), 0, fs, cl);
+        hipLaunchKernelGGL(k_setup_small, grid1(fm.ntris), dim3(256), 0, fs, fm.pos, fm.idx, fm.ntris, 1, 1, 0u, f->fog.ws, fc);
         uint32_t max_entries = 0;
         fa.tables_noise = plan_noise_tables(ctx, f, fc, &max_entries);
         if (max_entries) {
@@ -685,32 +698,47 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
                 plan.wg_begin[l + 1] = plan.wg_begin[l];
                 if (t.data) plan_table_level(plan, l, t.nx, t.ny, t.nz);
             }
-            hipLaunchKernelGGL(k_fog_tables, dim3(plan.wg_begin[16]), dim3(256), 0, ss, fa.tables_noise, plan);
+            hipLaunchKernelGGL(k_fog_tables, dim3(plan.wg_begin[16]), dim3(256), 0, fs, fa.tables_noise, plan);
         }
     }
-    WR_HIP(hipStreamWaitEvent(ss, f->ev_geom_done, 0));
-    if (prof) WR_HIP(hipEventRecord(ev[8], ss));
+    WR_HIP(hipStreamWaitEvent(fs, f->ev_geom_done, 0));
+    if (prof) WR_HIP(hipEventRecord(ev[8], fs));
+    const size_t npx = (size_t)ctx->W * ctx->H;
+    const uint32_t item_groups = (uint32_t)((npx + 255) / 256);
     if (fog_pass) {
         fa.fc = fc; fa.ws = f->fog.ws; fa.pos = fm.pos; fa.idx = fm.idx; fa.ntris = fm.ntris;
         fa.depth = f->d_depth; fa.color = f->d_color; fa.shadow = f->d_shadow; fa.tables = ctx->d_tables;
         fa.counters = ctx->d_counters;
         // the fog workspace has one bin and is not binned, so its bin_count and bin_cursor words
-        // are free: they count the march items and the pixels with several fog fragments
+        // are free: they count the march items and the pixels with several fog fragments; the
+        // word after its clip_count counts the lit fog points
         fa.item_count = f->fog.ws.bin_count; fa.item_pixel = f->d_fog_pixel; fa.item_ray = f->d_fog_ray;
-        fa.item_src = f->d_fog_src;
         fa.multi_count = f->fog.ws.bin_cursor; fa.multi_pixel = f->d_fog_multi;
-        dim3 mg((uint32_t)(((size_t)ctx->W * ctx->H + 63) / 64), 1, 1);
+        fa.lit_count = f->fog.ws.clip_count + 1; fa.lit_item = f->d_fog_lit;
+        fa.item_res = f->d_fog_res; fa.noise_view = f->d_fog_noise_view; fa.noise_light = f->d_fog_noise_light;
+        fa.cap = (uint32_t)npx;
         dim3 fg((uint32_t)(ctx->W + kFogBlock - 1) / kFogBlock, (uint32_t)(ctx->H + kFogBlock - 1) / kFogBlock, 1);
-        if (ctx->counting) hipLaunchKernelGGL(k_fog_setup<true>, fg, dim3(1024), 0, ss, fa);
-        else hipLaunchKernelGGL(k_fog_setup<false>, fg, dim3(1024), 0, ss, fa);
-        if (prof) WR_HIP(hipEventRecord(ev[6], ss));
-        if (ctx->counting) hipLaunchKernelGGL(k_fog_march<true>, mg, dim3(64), 0, ss, fa);
-        else hipLaunchKernelGGL(k_fog_march<false>, mg, dim3(64), 0, ss, fa);
+        if (ctx->counting) hipLaunchKernelGGL(k_fog_setup<true>, fg, dim3(1024), 0, fs, fa);
+        else hipLaunchKernelGGL(k_fog_setup<false>, fg, dim3(1024), 0, fs, fa);
+        if (prof) WR_HIP(hipEventRecord(ev[6], fs));
+        const dim3 vg(item_groups, (kFogMaxSteps + kFogStepGroup - 1) / kFogStepGroup, 1);
+        if (ctx->counting) hipLaunchKernelGGL(k_fog_noise_view<true>, vg, dim3(256), 0, fs, fa);
+        else hipLaunchKernelGGL(k_fog_noise_view<false>, vg, dim3(256), 0, fs, fa);
+        if (prof) WR_HIP(hipEventRecord(ev[9], fs));
+        WR_HIP(hipStreamWaitEvent(fs, f->ev_shadow_done, 0));
+        if (ctx->counting) hipLaunchKernelGGL(k_fog_view_resolve<true>, dim3(item_groups), dim3(256), 0, fs, fa);
+        else hipLaunchKernelGGL(k_fog_view_resolve<false>, dim3(item_groups), dim3(256), 0, fs, fa);
+        if (prof) WR_HIP(hipEventRecord(ev[10], fs));
+        const dim3 lg(item_groups, (kFogLightMaxSteps + kFogStepGroup - 1) / kFogStepGroup, 1);
+        if (ctx->counting) hipLaunchKernelGGL(k_fog_noise_light<true>, lg, dim3(256), 0, fs, fa);
+        else hipLaunchKernelGGL(k_fog_noise_light<false>, lg, dim3(256), 0, fs, fa);
     } else if (prof) {
-        WR_HIP(hipEventRecord(ev[6], ss));
+        WR_HIP(hipEventRecord(ev[6], fs));
+        WR_HIP(hipEventRecord(ev[9], fs));
+        WR_HIP(hipEventRecord(ev[10], fs));
     }
-    if (prof) WR_HIP(hipEventRecord(ev[5], ss));
-    WR_HIP(hipEventRecord(f->ev_join, ss));
+    if (prof) WR_HIP(hipEventRecord(ev[5], fs));
+    WR_HIP(hipEventRecord(f->ev_join, fs));
 
     // main stream: shading (reads the shadow maps)
     WR_HIP(hipStreamWaitEvent(ms, f->ev_shadow_done, 0));
@@ -730,7 +758,6 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
         LayerSink ls{f->blend.rp_slot, f->d_vis, f->blend.bin_flag, f->blend.lists, f->blend.list_count, f->blend.cap};
         hipLaunchKernelGGL((k_raster<kRasterLayers, kColorRasterThreads>), dim3((uint32_t)(ws.bins_x * ws.bins_y), 1, 1), dim3(kColorRasterThreads), 0,
                            ms, ws, ctx->W, ctx->H, (uint32_t*)nullptr, (float*)nullptr, fc.tile_rank, fc.tile_world, ls);
-        const size_t npx = (size_t)ctx->W * ctx->H;
         const uint32_t slot_groups = (uint32_t)std::min<size_t>((npx + 255) / 256, 2048);
         hipLaunchKernelGGL(k_resolve, dim3(slot_groups), dim3(256), 0, ms, sa);
         if (ctx->counting) hipLaunchKernelGGL(k_replay_slow<true>, dim3(256), dim3(64), 0, ms, sa);
@@ -743,7 +770,8 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
     // main stream: fog colours over the finished geometry colour
     WR_HIP(hipStreamWaitEvent(ms, f->ev_join, 0));
     if (fog_pass) {
-        hipLaunchKernelGGL(k_fog_blend, dim3(2048), dim3(256), 0, ms, fa);
+        if (ctx->counting) hipLaunchKernelGGL(k_fog_shade_blend<true>, dim3(2048), dim3(256), 0, ms, fa);
+        else hipLaunchKernelGGL(k_fog_shade_blend<false>, dim3(2048), dim3(256), 0, ms, fa);
         if (ctx->counting) hipLaunchKernelGGL(k_fog_multi<true>, dim3(1024), dim3(64), 0, ms, fa);
         else hipLaunchKernelGGL(k_fog_multi<false>, dim3(1024), dim3(64), 0, ms, fa);
     }
@@ -826,6 +854,7 @@ int wr_create(const WrConfig* config, WrContext** out_ctx) {
             FrameRes* f = &ctx->fr[k];
             WR_HIP(hipStreamCreateWithFlags(&f->ms, hipStreamNonBlocking));
             WR_HIP(hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
+            WR_HIP(hipStreamCreateWithFlags(&f->fs, hipStreamNonBlocking));
             hipEvent_t* evs[] = {&f->ev_fork, &f->ev_start, &f->ev_join, &f->ev_shadow_done, &f->ev_geom_done, &f->ev_done};
             for (hipEvent_t* e : evs) WR_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         }
@@ -860,6 +889,7 @@ void wr_destroy(WrContext* ctx) {
     for (FrameRes& f : ctx->fr) {
         if (f.ms) (void)hipStreamSynchronize(f.ms);
         if (f.side) (void)hipStreamSynchronize(f.side);
+        if (f.fs) (void)hipStreamSynchronize(f.fs);
     }
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_scene(ctx);
@@ -871,6 +901,7 @@ void wr_destroy(WrContext* ctx) {
         dfree(f.d_shadow); dfree(f.d_noise_pool);
         if (f.ms) (void)hipStreamDestroy(f.ms);
         if (f.side) (void)hipStreamDestroy(f.side);
+        if (f.fs) (void)hipStreamDestroy(f.fs);
         hipEvent_t evs[] = {f.ev_fork, f.ev_start, f.ev_join, f.ev_shadow_done, f.ev_geom_done, f.ev_done};
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     }
@@ -993,7 +1024,7 @@ int wr_render_frame_static(WrContext* ctx, const WrCameraUniform* camera, const 
         return fail(ctx, WR_ERR_UNSUPPORTED, "no static work buffer on this device");
     FrameRes sf;
     const FrameRes& own = ctx->fr[0];  // streams and events exist since wr_create
-    sf.ms = own.ms; sf.side = own.side;
+    sf.ms = own.ms; sf.side = own.side; sf.fs = own.fs;
     sf.ev_fork = own.ev_fork; sf.ev_start = own.ev_start; sf.ev_join = own.ev_join;
     sf.ev_shadow_done = own.ev_shadow_done; sf.ev_geom_done = own.ev_geom_done; sf.ev_done = own.ev_done;
     Arena sizing;
@@ -1139,25 +1170,27 @@ int wr_get_stats(WrContext* ctx, WrFrameStats* out) {
     if (ctx->ev_count > 0) {
         // shadow runs next to geometry and fog next to shade (side stream); shade includes any
         // wait for the shadow maps, the frame ends with the fog blend
-        const int a[6] = {1, 0, 3, 8, 0, 6}, b[6] = {2, 3, 4, 5, 7, 5};  // shadow, geometry, shade, fog, frame, march
-        double ms[6] = {0, 0, 0, 0, 0, 0};
+        const int a[7] = {1, 0, 3, 8, 0, 6, 10}, b[7] = {2, 3, 4, 5, 7, 9, 5};  // shadow, geometry, shade, fog, frame, view noise, light noise
+        double ms[7] = {0, 0, 0, 0, 0, 0, 0};
         for (int k = 0; k < ctx->ev_count; ++k)
-            for (int i = 0; i < 6; ++i) {
+            for (int i = 0; i < 7; ++i) {
                 float t = 0.0f;
                 WR_HIP(hipEventElapsedTime(&t, ctx->ev[k][a[i]], ctx->ev[k][b[i]]));
                 ms[i] += t;
             }
-        for (int i = 0; i < 6; ++i) ms[i] /= ctx->ev_count;
+        for (int i = 0; i < 7; ++i) ms[i] /= ctx->ev_count;
         ctx->stats.ms_shadow = (float)ms[0]; ctx->stats.ms_geometry = (float)ms[1];
         ctx->stats.ms_shade = (float)ms[2]; ctx->stats.ms_fog = (float)ms[3];
         ctx->stats.ms_total = (float)ms[4];
         ctx->stats.ms_fog_march = (float)ms[5];
+        ctx->stats.ms_fog_light_march = (float)ms[6];
         ctx->stats.profiled_frames = (uint32_t)ctx->ev_count;
     }
     unsigned long long c[8];
     WR_HIP(hipMemcpy(c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
     ctx->stats.fog_fragments = c[0]; ctx->stats.fog_noise_evals = c[1];
     ctx->stats.shaded_fragments = c[2]; ctx->stats.replay_pixels = c[3]; ctx->stats.replay_slow_pixels = c[4];
+    ctx->stats.fog_noise_evals_view = c[5]; ctx->stats.fog_noise_evals_light = c[6];
     *out = ctx->stats;
     return WR_OK;
 }

@@ -801,37 +801,74 @@ WR_HD float fog_max_depth(const FrameConsts& fc, const float* depth_tex, float f
     return geometry_depth - volume_depth;
 }
 
-// fog.wgsl:127-128,138-165 (ray_march_fog 87-116 inlined): the march and the fog colour for
-// a fragment whose max_fog_depth is positive.
-WR_HD V4 fog_march_shade(const FrameConsts& fc, const ShadowMap& sm, const NoiseTables* nt, V3 origin, float max_fog_depth,
-                         uint32_t& evals) {
-    V3 cam = v3(fc.cam_pos[0], fc.cam_pos[1], fc.cam_pos[2]);
+// ray_march with the noise of its steps evaluated beforehand (noise_at(i) returns what
+// fog_noise gives at origin + dir * depth_i): the same loop, the same additions, the same exits.
+template <class NoiseAt>
+WR_HD V2 ray_march_stored(float max_depth, int max_steps, float step_size, float fog_density, NoiseAt noise_at, uint32_t& evals) {
+    float density = 0.0f, depth = 0.0f;
+    float contribution = fog_density / (float)max_steps;
+    for (int i = 0; i < max_steps; ++i) {
+        depth += step_size;
+        if (depth >= max_depth) break;
+        float noise = noise_at(i);
+        ++evals;
+        density += noise * contribution;
+        if (density >= 1.0f) { density = 1.0f; break; }
+    }
+    return V2{density, depth};
+}
+// Value of `depth` in step i of ray_march (i from 0): step_size added i + 1 times to 0.  The
+// step sizes of constants.wgsl are the integers 5 and 10 and there are at most 30 steps, so
+// every partial sum is an integer below 2^24 and the product below is that sum exactly.
+WR_HD float march_step_depth(float step_size, int i) { return step_size * (float)(i + 1); }
+static_assert(kFogStepSize == 5.0f && kFogLightStepSize == 10.0f && kFogMaxSteps <= 30 && kFogLightMaxSteps <= 30,
+              "march_step_depth relies on integer step sizes");
+
+// Where the light march of fog.wgsl:150-159 starts and which way it goes.
+struct LightRay { V3 origin, dir; float max_dist; };
+WR_HD LightRay fog_light_ray(const FrameConsts& fc, V3 fog_end) {
     V3 lp = v3(fc.light_pos[0], fc.light_pos[1], fc.light_pos[2]);
-    V3 direction = normalize3(origin - cam);
-    V2 fm = ray_march(fc, nt, origin, direction, max_fog_depth, kFogMaxSteps, kFogStepSize, kFogDensity, evals);
-    float fog_density = fm.x, fog_depth = fm.y;
-    V3 fog_end = origin + direction * fog_depth;
-    V3 fog_position = origin + direction * fog_depth;
+    V3 to_light = lp - fog_end;
+    float max_light_dist = length3(to_light);
+    return LightRay{fog_end, to_light / max_light_dist, max_light_dist};
+}
+// fog.wgsl:138-165 after both marches: the fog colour.  `occlusion` is read only for a lit
+// fog point (in_light > 0), as in the shader.
+WR_HD V4 fog_shade(const FrameConsts& fc, V3 fog_position, float fog_density, float in_light, float occlusion) {
+    V3 lp = v3(fc.light_pos[0], fc.light_pos[1], fc.light_pos[2]);
     float light_dist = length3(lp - fog_position);
     float bc = mixf(kFogDensityColorX, kFogDensityColorY, fog_density);
     V3 ambient = sample_ambient_light(fc.light_color, light_dist, 1.0f) * 2.0f;
     ambient = ambient * v3(bc, bc, bc);
     V3 radiance = v3(0.0f, 0.0f, 0.0f);
-    float in_light = sample_direct_light(fc, sm, V4{fog_position.x, fog_position.y, fog_position.z, 1.0f});
     if (in_light > 0.0f) {
-        // The light march (fog.wgsl:150-159) only feeds `occlusion`, which only this branch
-        // reads: a fog point in shadow does not need it, and it is not run for one.
-        V3 to_light = lp - fog_end;
-        float max_light_dist = length3(to_light);
-        V3 light_direction = to_light / max_light_dist;
-        V2 lm = ray_march(fc, nt, fog_end, light_direction, max_light_dist, kFogLightMaxSteps, kFogLightStepSize, kFogLightDensity, evals);
-        float occlusion = lm.x;
         float att = 1.0f / (1.0f + light_dist * light_dist);
         radiance = (((v3(fc.light_color[0], fc.light_color[1], fc.light_color[2]) * fc.light_color[3]) * att) * in_light) * (1.0f - occlusion);
     }
     V3 result = ambient + radiance;
     result = result / (result + v3(1.0f, 1.0f, 1.0f));
     return V4{result.x, result.y, result.z, fog_density * kFogAlpha};
+}
+
+// fog.wgsl:127-128,138-165 (ray_march_fog 87-116 inlined): the march and the fog colour for
+// a fragment whose max_fog_depth is positive.
+WR_HD V4 fog_march_shade(const FrameConsts& fc, const ShadowMap& sm, const NoiseTables* nt, V3 origin, float max_fog_depth,
+                         uint32_t& evals) {
+    V3 cam = v3(fc.cam_pos[0], fc.cam_pos[1], fc.cam_pos[2]);
+    V3 direction = normalize3(origin - cam);
+    V2 fm = ray_march(fc, nt, origin, direction, max_fog_depth, kFogMaxSteps, kFogStepSize, kFogDensity, evals);
+    float fog_density = fm.x, fog_depth = fm.y;
+    V3 fog_position = origin + direction * fog_depth;  // fog_end and fog_position of the shader are this one point
+    float in_light = sample_direct_light(fc, sm, V4{fog_position.x, fog_position.y, fog_position.z, 1.0f});
+    float occlusion = 0.0f;
+    if (in_light > 0.0f) {
+        // The light march (fog.wgsl:150-159) only feeds `occlusion`, which only the lit branch
+        // reads: a fog point in shadow does not need it, and it is not run for one.
+        LightRay lr = fog_light_ray(fc, fog_position);
+        V2 lm = ray_march(fc, nt, lr.origin, lr.dir, lr.max_dist, kFogLightMaxSteps, kFogLightStepSize, kFogLightDensity, evals);
+        occlusion = lm.x;
+    }
+    return fog_shade(fc, fog_position, fog_density, in_light, occlusion);
 }
 
 }  // namespace wr

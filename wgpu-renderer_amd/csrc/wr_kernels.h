@@ -10,8 +10,9 @@
 //   shade    : k_shade -> k_raster<kRasterLayers> -> k_resolve -> k_replay_slow ->
 //              k_shade_frags -> k_blend
 //              (deferred pbr.wgsl fragment stage; ordered blending of translucent fronts)
-//   fog      : k_setup_small(fog) -> k_fog_tables -> k_fog_setup -> k_fog_march ->
-//              k_fog_blend (+ k_fog_multi)                        (fog.wgsl fragment stage)
+//   fog      : k_setup_small(fog) -> k_fog_tables -> k_fog_setup -> k_fog_noise_view ->
+//              k_fog_view_resolve -> k_fog_noise_light -> k_fog_shade_blend (+ k_fog_multi)
+//                                                                 (fog.wgsl fragment stage)
 //
 // The rasteriser is tile-binned: the target is cut into 64x64-pixel bins, every set-up
 // triangle is appended to the list of each bin it can touch, and one workgroup per bin
@@ -724,7 +725,8 @@ struct ShadeArgs {
     const uint32_t* texels;
     const float* tables;
     const float* shadow;
-    unsigned long long* counters;  // [0] fog fragments [1] noise evals [2] shaded fragments [3] replay pixels [4] slow-path pixels
+    unsigned long long* counters;  // [0] fog fragments [1] noise evals the marches read [2] shaded fragments [3] replay pixels [4] slow-path pixels
+                                   // [5] noise evals of k_fog_noise_view [6] of k_fog_noise_light
     BlendWS bw;
 };
 
@@ -1038,7 +1040,12 @@ struct FogArgs {
     uint32_t* item_pixel;  // [W*H] pixel index of each item
     float4* item_ray;      // [W*H] ray origin xyz + max_fog_depth
     NoiseTables tables_noise;  // hash tables of the low octaves (k_fog_tables)
-    float4* item_src;      // [W*H] fog colour of each item (k_fog_march -> k_fog_blend)
+    float* noise_view;     // [kFogMaxSteps][cap] fog_noise of view-march step s of item k at s * cap + k
+    float* noise_light;    // [kFogLightMaxSteps][cap] the same for the light march, indexed by position in the lit list
+    float4* item_res;      // [cap] view march of an item: density, depth, in_light, position in the lit list (bits)
+    uint32_t* lit_count;   // items whose fog point is lit (they need the light march)
+    uint32_t* lit_item;    // [cap] their item indices
+    uint32_t cap;          // W*H
     uint32_t* multi_count; // pixels with several fog fragments, finished by k_fog_multi
     uint32_t* multi_pixel; // [W*H]
 };
@@ -1083,7 +1090,7 @@ static_assert(sizeof(StagedRec) == 88, "StagedRec layout");
 // stage those that can touch the block in LDS (edge set-up done once per record, not once
 // per pixel); then every pixel tests the staged records.  A pixel with exactly one fog
 // fragment (always the case for a convex volume) whose march is not empty becomes a work
-// item for k_fog_march, appended with one atomic per workgroup; a pixel with several
+// item for the march kernels, appended with one atomic per workgroup; a pixel with several
 // fragments is queued for k_fog_multi.  Reads the geometry depth only, not the colour, so the
 // fog pass up to and including the march can run next to the shading kernels.
 constexpr int kFogBlock = 32;
@@ -1261,33 +1268,128 @@ __global__ __launch_bounds__(256) void k_fog_tables(NoiseTables nt, TablePlan pl
     const_cast<float*>(t.data)[i] = lattice_hash((float)(t.lox + ix), (float)(t.loy + iy), (float)(t.loz + iz));
 }
 
-// Fog pass, part 2: one thread per work item runs both marches of fog.wgsl and stores the fog
-// colour of the item.  One wavefront per workgroup, all lanes busy, so the long-running
-// marches spread evenly over the chip.
-template <bool COUNT>
-__global__ __launch_bounds__(64) void k_fog_march(FogArgs a) {
-    const uint32_t k = blockIdx.x * 64u + threadIdx.x;
-    if (k >= *a.item_count) return;
-    const float4 ray = a.item_ray[k];
-    ShadowMap sm{a.shadow, a.fc.S};
-    uint32_t evals = 0;
-    V4 src = fog_march_shade(a.fc, sm, &a.tables_noise, v3(ray.x, ray.y, ray.z), ray.w, evals);
-    if (COUNT) atomicAdd(&a.counters[1], (unsigned long long)evals);
-    a.item_src[k] = make_float4(src.x, src.y, src.z, src.w);
+// Fog pass, part 2: the marches of fog.wgsl:64-116, cut at their only sequential dependence.
+// The steps of a march depend on each other through two scalars only (the running density and
+// the loop exits); the expensive part, fog_noise at the step's position, depends on the step
+// index alone, because `depth` is step_size added i + 1 times (march_step_depth).  So the noise
+// of every step the depth exit allows is evaluated first, one (item, step) pair per lane, in
+// uniform work units that fill the chip evenly; the running sums are then formed from the
+// stored values by the loop of the shader itself (ray_march_stored).  A step that the density
+// exit (density >= 1) would have skipped is evaluated and not read: that needs more than
+// fifteen steps of noise above one half and is rare.
+//   k_fog_noise_view   fog_noise of the view-march steps          (needs geometry depth only)
+//   k_fog_view_resolve running sums, fog point, its shadow lookup (needs the shadow maps);
+//                      lit fog points are listed for the light march
+//   k_fog_noise_light  fog_noise of the light-march steps of lit fog points
+//   k_fog_shade_blend  occlusion sums, fog colour, blend over the finished geometry colour
+#ifndef WR_FOG_STEP_GROUP
+#define WR_FOG_STEP_GROUP 5
+#endif
+constexpr int kFogStepGroup = WR_FOG_STEP_GROUP;  // march steps one wavefront evaluates for its 64 items
+
+__device__ inline V3 fog_item_dir(const FrameConsts& fc, V3 origin) {  // fog.wgsl:127
+    return normalize3(origin - v3(fc.cam_pos[0], fc.cam_pos[1], fc.cam_pos[2]));
 }
 
-// Fog pass, part 3: blends the marched fog colours over the finished geometry colour
-// (SrcAlpha / OneMinusSrcAlpha, state.rs:501).
-__global__ __launch_bounds__(256) void k_fog_blend(FogArgs a) {
+// grid.x: 256 items per workgroup (each wavefront on its own), grid.y: group of steps
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_fog_noise_view(FogArgs a) {
+    const uint32_t n = *a.item_count;
+    if ((blockIdx.x * 256u + (threadIdx.x & ~63u)) >= n) return;
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    const bool live = k < n;
+    const float4 ray = live ? a.item_ray[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const V3 origin = v3(ray.x, ray.y, ray.z);
+    const V3 dir = fog_item_dir(a.fc, origin);
+    const int s0 = (int)blockIdx.y * kFogStepGroup;
+#pragma unroll 1
+    for (int s = s0; s < s0 + kFogStepGroup && s < kFogMaxSteps; ++s) {
+        const float depth = march_step_depth(kFogStepSize, s);
+        const bool act = live && !(depth >= ray.w);  // the march's exit test, fog.wgsl:70-72
+        if (!__any(act ? 1 : 0)) break;              // depth only grows: no later step is active either
+        if (act) a.noise_view[(size_t)s * a.cap + k] = fog_noise_tab(a.fc, a.tables_noise, origin + dir * depth);
+        if (COUNT && act) atomicAdd(&a.counters[5], 1ull);
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_fog_view_resolve(FogArgs a) {
+    __shared__ uint32_t s_cnt, s_base;
+    const uint32_t n = *a.item_count;
+    if (blockIdx.x * 256u >= n) return;
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    const bool live = k < n;
+    V2 fm = V2{0.0f, 0.0f};
+    float in_light = 0.0f;
+    if (live) {
+        const float4 ray = a.item_ray[k];
+        const V3 origin = v3(ray.x, ray.y, ray.z);
+        const V3 dir = fog_item_dir(a.fc, origin);
+        uint32_t evals = 0;
+        const float* nv = a.noise_view + k;
+        const size_t cap = a.cap;
+        fm = ray_march_stored(ray.w, kFogMaxSteps, kFogStepSize, kFogDensity, [nv, cap](int i) { return nv[(size_t)i * cap]; }, evals);
+        const V3 fp = origin + dir * fm.y;
+        ShadowMap sm{a.shadow, a.fc.S};
+        in_light = sample_direct_light(a.fc, sm, V4{fp.x, fp.y, fp.z, 1.0f});
+        if (COUNT) atomicAdd(&a.counters[1], (unsigned long long)evals);
+    }
+    const bool lit = live && in_light > 0.0f;
+    const uint32_t j = group_append(a.lit_count, lit ? 1u : 0u, &s_cnt, &s_base);
+    if (lit) a.lit_item[j] = k;
+    if (live) a.item_res[k] = make_float4(fm.x, fm.y, in_light, u2f(lit ? j : 0xFFFFFFFFu));
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_fog_noise_light(FogArgs a) {
+    const uint32_t n = *a.lit_count;
+    if ((blockIdx.x * 256u + (threadIdx.x & ~63u)) >= n) return;
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    const bool live = j < n;
+    const uint32_t k = live ? a.lit_item[j] : 0u;
+    const float4 ray = a.item_ray[k];
+    const float4 res = a.item_res[k];
+    const V3 origin = v3(ray.x, ray.y, ray.z);
+    const V3 dir = fog_item_dir(a.fc, origin);
+    const LightRay lr = fog_light_ray(a.fc, origin + dir * res.y);
+    const int s0 = (int)blockIdx.y * kFogStepGroup;
+#pragma unroll 1
+    for (int s = s0; s < s0 + kFogStepGroup && s < kFogLightMaxSteps; ++s) {
+        const float depth = march_step_depth(kFogLightStepSize, s);
+        const bool act = live && !(depth >= lr.max_dist);
+        if (!__any(act ? 1 : 0)) break;
+        if (act) a.noise_light[(size_t)s * a.cap + j] = fog_noise_tab(a.fc, a.tables_noise, lr.origin + lr.dir * depth);
+        if (COUNT && act) atomicAdd(&a.counters[6], 1ull);
+    }
+}
+
+// Blends SrcAlpha / OneMinusSrcAlpha over the finished geometry colour (state.rs:501).
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_fog_shade_blend(FogArgs a) {
     __shared__ float s_tab[768];
     const uint32_t n = *a.item_count;
     if (blockIdx.x * 256u >= n) return;
     stage_color_tables(s_tab, a.tables);
     ColorTables ct{s_tab};
     for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n; k += gridDim.x * 256u) {
+        const float4 ray = a.item_ray[k];
+        const float4 res = a.item_res[k];
+        const V3 origin = v3(ray.x, ray.y, ray.z);
+        const V3 fp = origin + fog_item_dir(a.fc, origin) * res.y;
+        const float in_light = res.z;
+        float occlusion = 0.0f;
+        if (in_light > 0.0f) {
+            const LightRay lr = fog_light_ray(a.fc, fp);
+            uint32_t evals = 0;
+            const float* nl = a.noise_light + f2u(res.w);
+            const size_t cap = a.cap;
+            occlusion = ray_march_stored(lr.max_dist, kFogLightMaxSteps, kFogLightStepSize, kFogLightDensity,
+                                         [nl, cap](int i) { return nl[(size_t)i * cap]; }, evals).x;
+            if (COUNT) atomicAdd(&a.counters[1], (unsigned long long)evals);
+        }
+        const V4 src = fog_shade(a.fc, fp, res.x, in_light, occlusion);
         const uint32_t pi = a.item_pixel[k];
-        const float4 c = a.item_src[k];
-        a.color[pi] = blend_pack(ct, a.color[pi], V4{c.x, c.y, c.z, c.w}, true);
+        a.color[pi] = blend_pack(ct, a.color[pi], src, true);
     }
 }
 
