@@ -11,8 +11,10 @@ using namespace wr;
 __global__ void k_hc_hash(const float* d, int n, float* out_guarded, float* out_unguarded) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    out_guarded[i] = hash_from_dot<true>(d[i]);
-    out_unguarded[i] = hash_from_dot<false>(d[i]);
+    out_guarded[i] = hash_from_dot<kSinGuarded>(d[i]);
+    // the unguarded forms, each where its caller may use it (elsewhere the guarded value is passed on)
+    const float ad = fabsf(d[i]);
+    out_unguarded[i] = ad <= kSinFastRange ? hash_from_dot<kSinFast>(d[i]) : hash_from_dot<kSinInt>(d[i]);
 }
 __global__ void k_hc_sin(const float* x, int n, float* out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -74,6 +76,19 @@ long long hc_dev_fract_mismatches() {
     return (long long)m;
 }
 float hc_hash_from_dot(float d) { return hash_from_dot<true>(d); }
+// Host build of the product's sine: floats with bit patterns lo_bits + phase, + stride, ... below
+// hi_bits (both signs) for which the fast form and the guarded form differ.
+unsigned long long hc_sin_fast_mismatches(unsigned lo_bits, unsigned hi_bits, unsigned stride, unsigned phase) {
+    unsigned long long bad = 0;
+    for (unsigned long long b = (unsigned long long)lo_bits + phase; b < hi_bits; b += stride)
+        for (unsigned sg = 0; sg < 2; ++sg) {
+            const float x = u2f((unsigned)b | (sg << 31));
+            if (f2u(wr_sin_t<kSinFast>(x)) != f2u(wr_sin_t<kSinGuarded>(x))) ++bad;
+            if (f2u(wr_sin_t<kSinInt>(x)) != f2u(wr_sin_t<kSinGuarded>(x))) ++bad;
+        }
+    return bad;
+}
+float hc_sin_fast_range() { return kSinFastRange; }
 float hc_sin(float x) { return wr_sin(x); }
 float hc_value_noise(const float* p) { return value_noise(v3(p[0], p[1], p[2])); }
 float hc_fbm(const float* p) { return fbm(v3(p[0], p[1], p[2])); }

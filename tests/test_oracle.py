@@ -326,6 +326,20 @@ def test_product_arithmetic_is_bit_identical_to_oracle(hc):
         assert hc.hc_depth_to_linear(float(d), 1.0, 3000.0) == L.wro_depth_to_linear(float(d), 1.0, 3000.0)
 
 
+def test_product_fast_sine_forms_equal_the_guarded_form_on_every_float_of_their_range(hc):
+    """The hot path uses the form of the sine whose octant arithmetic stays in floating point,
+    allowed for |x| <= 13176794; every float of that range (both signs) is compared here with the
+    guarded form, which the tests above compare with the oracle."""
+    from concurrent.futures import ThreadPoolExecutor
+    hc.hc_sin_fast_mismatches.restype = C.c_ulonglong
+    hc.hc_sin_fast_mismatches.argtypes = [C.c_uint] * 4
+    hc.hc_sin_fast_range.restype = C.c_float
+    hi = bits(hc.hc_sin_fast_range()) + 1
+    with ThreadPoolExecutor(8) as ex:
+        bad = sum(ex.map(lambda t: hc.hc_sin_fast_mismatches(0, hi, 8, t), range(8)))
+    assert bad == 0
+
+
 def test_product_triangle_setup_is_bit_identical_to_oracle(hc):
     """Random triangles around a perspective camera, many crossing the near plane or the
     guard band: same sub-triangles, same snapped vertices, depth planes, clip weights and

@@ -16,6 +16,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -598,6 +599,9 @@ NoiseTables plan_noise_tables(const WrContext* ctx, const FrameRes* f, const Fra
     NoiseTables nt;
     memset(&nt, 0, sizeof(nt));
     *max_entries = 0;
+#ifdef WR_DEV
+    for (int l = 0; l < 16; ++l) nt.level[l].dbg_level = l;
+#endif
     double lo[3], hi[3];
     if (!fog_sample_bounds(ctx, fc, lo, hi)) return nt;
     const double grow = 0.0;
@@ -624,23 +628,30 @@ NoiseTables plan_noise_tables(const WrContext* ctx, const FrameRes* f, const Fra
     return nt;
 }
 
-// One frame on three streams.  Main: geometry pass, shading (after the shadow maps), fog blend.
-// Side: the six shadow passes.  Fog: fog volume set-up and noise tables (they need the frame
-// constants only), then, once the geometry depth exists, the view march (depth and tables, no
-// shadow maps), and after the shadow maps the fog points' shadow lookups and the light march.
-// So the dominant kernel starts as soon as the geometry raster is done and runs next to the
-// shadow passes and the shading kernels.
+// One frame.  Main stream: geometry pass, shading (after the shadow maps), fog blend.  Side
+// stream: the six shadow passes.  The fog pass has two schedules:
+//  * one frame in flight (the frame has the device to itself): a third stream takes the fog
+//    volume set-up and the noise tables (they need the frame constants only), then, once the
+//    geometry depth exists, the view march (k_fog_noise_view: depth and tables, no shadow
+//    maps), and after the shadow maps the fog points' shadow lookups and the light march.  The
+//    dominant kernel starts as soon as the geometry raster is done, runs next to the shadow
+//    passes and the shading kernels, and its evenly sized work units fill the chip to its end;
+//  * several frames in flight: the fog pass follows the shadow passes on the side stream and
+//    marches each item in one piece (k_fog_march); the neighbouring frames' kernels fill the
+//    device around it (measured on one machine: 968 against 889 frames/s with four frames in
+//    flight, 757 against 782 with one).
 // Profiling events of a frame: [0] frame start, [3] geometry end, [4] shade end, [7] frame end
 // on the main stream; [1] shadow start, [2] shadow end on the side stream; [8] fog start,
-// [6] view-march noise start, [9] its end, [10] light-march noise start, [5] its end on the fog
-// stream.
+// [6] view-march noise (or k_fog_march) start, [9] its end, [10] light-march noise start,
+// [5] its end on the fog stream.
 int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t passes, bool do_shadow) {
     const ModelDev& g = ctx->dev[WR_MODEL_GEOMETRY];
     const ModelDev& lm = ctx->dev[WR_MODEL_LIGHT_MARKER];
     const ModelDev& fm = ctx->dev[WR_MODEL_FOG_VOLUME];
     const bool prof = ctx->profiling;
     hipEvent_t* ev = ctx->ev[ctx->ev_next];
-    hipStream_t ms = f->ms, ss = f->side, fs = f->fs;
+    const bool latency_schedule = ctx->nfr == 1;
+    hipStream_t ms = f->ms, ss = f->side, fs = latency_schedule ? f->fs : f->side;
     int rc;
     // order the frame after what the caller has queued on its stream so far
     WR_HIP(hipEventRecord(f->ev_fork, ctx->stream));
@@ -651,55 +662,74 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
     // after this set's previous frame and the caller's earlier work
     WR_HIP(hipEventRecord(f->ev_start, ms));
     WR_HIP(hipStreamWaitEvent(ss, f->ev_start, 0));
-    WR_HIP(hipStreamWaitEvent(fs, f->ev_start, 0));
+    if (fs != ss) WR_HIP(hipStreamWaitEvent(fs, f->ev_start, 0));
 
-    // main stream: geometry + light marker -> visibility / depth
-    {
-        ClearList cl{};
-        cl.ptr[0] = f->geom.counters; cl.words[0] = (uint32_t)(f->geom.counters_bytes / 4);
-        cl.ptr[1] = f->blend.counts; cl.words[1] = (uint32_t)(f->blend_clear_bytes / 4);
-        hipLaunchKernelGGL(k_clear_words, dim3(8), dim3(256), 0, ms, cl);
-    }
-    VertexIn vin{g.pos, g.uv, g.nrm, g.tan, g.bit, g.nv};
-    hipLaunchKernelGGL(k_vs_geometry, grid1(g.nv), dim3(256), 0, ms, vin, f->vout, fc);
-    hipLaunchKernelGGL(k_setup<false>, grid1(g.ntris, 1), dim3(256), 0, ms, f->vout.clip, g.nv, g.idx, g.ntris,
-                       f->geom.ws, ctx->W, ctx->H, fc.tile_rank, fc.tile_world);
-    hipLaunchKernelGGL(k_setup_clip<false>, dim3(256, 1, 1), dim3(64), 0, ms, f->vout.clip, g.nv, g.idx, f->geom.ws,
-                       ctx->W, ctx->H, fc.tile_rank, fc.tile_world);
-    if (lm.ntris)
-        hipLaunchKernelGGL(k_setup_small, grid1(lm.ntris), dim3(256), 0, ms, lm.pos, lm.idx, lm.ntris, 0,
-                           (passes & WR_PASS_LIGHT_DEBUG) ? 1 : 0, g.ntris, f->geom.ws, fc);
-    if ((rc = bin_and_raster(ctx, f, ms, f->geom, false, fc.tile_rank, fc.tile_world)) != WR_OK) return rc;
-    if (prof) WR_HIP(hipEventRecord(ev[3], ms));
-    WR_HIP(hipEventRecord(f->ev_geom_done, ms));
-
-    // side stream: shadow maps
-    if (prof) WR_HIP(hipEventRecord(ev[1], ss));
-    if (do_shadow && (passes & WR_PASS_SHADOWS))
-        if ((rc = shadow_stage(ctx, f, ss, fc)) != WR_OK) return rc;
-    if (prof) WR_HIP(hipEventRecord(ev[2], ss));
-    WR_HIP(hipEventRecord(f->ev_shadow_done, ss));
-
-    // fog stream
+    // Submission takes the host about as long as the device needs for half a frame, so the
+    // order of the two independent chains matters: the one the frame's critical path starts
+    // with goes first (one frame in flight: geometry, which the view march waits for; frames
+    // overlapping: the shadow passes, the longer chain, which shading waits for).
+    auto submit_geometry = [&]() -> int {
+        // main stream: geometry + light marker -> visibility / depth
+        {
+            ClearList cl{};
+            cl.ptr[0] = f->geom.counters; cl.words[0] = (uint32_t)(f->geom.counters_bytes / 4);
+            cl.ptr[1] = f->blend.counts; cl.words[1] = (uint32_t)(f->blend_clear_bytes / 4);
+            hipLaunchKernelGGL(k_clear_words, dim3(8), dim3(256), 0, ms, cl);
+        }
+        VertexIn vin{g.pos, g.uv, g.nrm, g.tan, g.bit, g.nv};
+        hipLaunchKernelGGL(k_vs_geometry, grid1(g.nv), dim3(256), 0, ms, vin, f->vout, fc);
+        hipLaunchKernelGGL(k_setup<false>, grid1(g.ntris, 1), dim3(256), 0, ms, f->vout.clip, g.nv, g.idx, g.ntris,
+                           f->geom.ws, ctx->W, ctx->H, fc.tile_rank, fc.tile_world);
+        hipLaunchKernelGGL(k_setup_clip<false>, dim3(256, 1, 1), dim3(64), 0, ms, f->vout.clip, g.nv, g.idx, f->geom.ws,
+                           ctx->W, ctx->H, fc.tile_rank, fc.tile_world);
+        if (lm.ntris)
+            hipLaunchKernelGGL(k_setup_small, grid1(lm.ntris), dim3(256), 0, ms, lm.pos, lm.idx, lm.ntris, 0,
+                               (passes & WR_PASS_LIGHT_DEBUG) ? 1 : 0, g.ntris, f->geom.ws, fc);
+        if ((rc = bin_and_raster(ctx, f, ms, f->geom, false, fc.tile_rank, fc.tile_world)) != WR_OK) return rc;
+        if (prof) WR_HIP(hipEventRecord(ev[3], ms));
+        WR_HIP(hipEventRecord(f->ev_geom_done, ms));
+        return WR_OK;
+    };
+    auto submit_shadows = [&]() -> int {
+        // side stream: shadow maps
+        if (prof) WR_HIP(hipEventRecord(ev[1], ss));
+        if (do_shadow && (passes & WR_PASS_SHADOWS))
+            if ((rc = shadow_stage(ctx, f, ss, fc)) != WR_OK) return rc;
+        if (prof) WR_HIP(hipEventRecord(ev[2], ss));
+        WR_HIP(hipEventRecord(f->ev_shadow_done, ss));
+        return WR_OK;
+    };
+    // fog volume set-up and noise tables: they need the frame constants only
     FogArgs fa;
     memset(&fa, 0, sizeof(fa));
-    if (fog_pass) {
-        ClearList cl{};
-        cl.ptr[0] = f->fog.counters; cl.words[0] = (uint32_t)(f->fog.counters_bytes / 4);
-        hipLaunchKernelGGL(k_clear_words, dim3(8), dim3(256), 0, fs, cl);
-        hipLaunchKernelGGL(k_setup_small, grid1(fm.ntris), dim3(256), 0, fs, fm.pos, fm.idx, fm.ntris, 1, 1, 0u, f->fog.ws, fc);
-        uint32_t max_entries = 0;
-        fa.tables_noise = plan_noise_tables(ctx, f, fc, &max_entries);
-        if (max_entries) {
-            TablePlan plan{};
-            for (int l = 0; l < 16; ++l) {
-                const NoiseTable& t = fa.tables_noise.level[l];
-                plan.xchunks[l] = plan.ychunks[l] = 1u;
-                plan.wg_begin[l + 1] = plan.wg_begin[l];
-                if (t.data) plan_table_level(plan, l, t.nx, t.ny, t.nz);
+    auto submit_fog_prologue = [&]() {
+        if (fog_pass) {
+            ClearList cl{};
+            cl.ptr[0] = f->fog.counters; cl.words[0] = (uint32_t)(f->fog.counters_bytes / 4);
+            hipLaunchKernelGGL(k_clear_words, dim3(8), dim3(256), 0, fs, cl);
+            hipLaunchKernelGGL(k_setup_small, grid1(fm.ntris), dim3(256), 0, fs, fm.pos, fm.idx, fm.ntris, 1, 1, 0u, f->fog.ws, fc);
+            uint32_t max_entries = 0;
+            fa.tables_noise = plan_noise_tables(ctx, f, fc, &max_entries);
+            if (max_entries) {
+                TablePlan plan{};
+                for (int l = 0; l < 16; ++l) {
+                    const NoiseTable& t = fa.tables_noise.level[l];
+                    plan.xchunks[l] = plan.ychunks[l] = 1u;
+                    plan.wg_begin[l + 1] = plan.wg_begin[l];
+                    if (t.data) plan_table_level(plan, l, t.nx, t.ny, t.nz);
+                }
+                hipLaunchKernelGGL(k_fog_tables, dim3(plan.wg_begin[16]), dim3(256), 0, fs, fa.tables_noise, plan);
             }
-            hipLaunchKernelGGL(k_fog_tables, dim3(plan.wg_begin[16]), dim3(256), 0, fs, fa.tables_noise, plan);
         }
+    };
+    if (latency_schedule) {
+        if ((rc = submit_geometry()) != WR_OK) return rc;
+        submit_fog_prologue();
+        if ((rc = submit_shadows()) != WR_OK) return rc;
+    } else {
+        if ((rc = submit_shadows()) != WR_OK) return rc;
+        if ((rc = submit_geometry()) != WR_OK) return rc;
+        submit_fog_prologue();
     }
     WR_HIP(hipStreamWaitEvent(fs, f->ev_geom_done, 0));
     if (prof) WR_HIP(hipEventRecord(ev[8], fs));
@@ -721,17 +751,28 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
         if (ctx->counting) hipLaunchKernelGGL(k_fog_setup<true>, fg, dim3(1024), 0, fs, fa);
         else hipLaunchKernelGGL(k_fog_setup<false>, fg, dim3(1024), 0, fs, fa);
         if (prof) WR_HIP(hipEventRecord(ev[6], fs));
-        const dim3 vg(item_groups, (kFogMaxSteps + kFogStepGroup - 1) / kFogStepGroup, 1);
-        if (ctx->counting) hipLaunchKernelGGL(k_fog_noise_view<true>, vg, dim3(256), 0, fs, fa);
-        else hipLaunchKernelGGL(k_fog_noise_view<false>, vg, dim3(256), 0, fs, fa);
-        if (prof) WR_HIP(hipEventRecord(ev[9], fs));
-        WR_HIP(hipStreamWaitEvent(fs, f->ev_shadow_done, 0));
-        if (ctx->counting) hipLaunchKernelGGL(k_fog_view_resolve<true>, dim3(item_groups), dim3(256), 0, fs, fa);
-        else hipLaunchKernelGGL(k_fog_view_resolve<false>, dim3(item_groups), dim3(256), 0, fs, fa);
-        if (prof) WR_HIP(hipEventRecord(ev[10], fs));
-        const dim3 lg(item_groups, (kFogLightMaxSteps + kFogStepGroup - 1) / kFogStepGroup, 1);
-        if (ctx->counting) hipLaunchKernelGGL(k_fog_noise_light<true>, lg, dim3(256), 0, fs, fa);
-        else hipLaunchKernelGGL(k_fog_noise_light<false>, lg, dim3(256), 0, fs, fa);
+        if (latency_schedule) {
+            const dim3 vg(item_groups * (uint32_t)kFogViewGroups, 1, 1);
+            if (ctx->counting) hipLaunchKernelGGL(k_fog_noise_view<true>, vg, dim3(256), 0, fs, fa);
+            else hipLaunchKernelGGL(k_fog_noise_view<false>, vg, dim3(256), 0, fs, fa);
+            if (prof) WR_HIP(hipEventRecord(ev[9], fs));
+            WR_HIP(hipStreamWaitEvent(fs, f->ev_shadow_done, 0));
+            if (ctx->counting) hipLaunchKernelGGL(k_fog_view_resolve<true>, dim3(item_groups), dim3(256), 0, fs, fa);
+            else hipLaunchKernelGGL(k_fog_view_resolve<false>, dim3(item_groups), dim3(256), 0, fs, fa);
+            if (prof) WR_HIP(hipEventRecord(ev[10], fs));
+#ifdef WR_DEV
+            for (int l = 0; l < 16; ++l) fa.tables_noise.level[l].dbg_level = 256 + l;
+#endif
+            const dim3 lg(item_groups * (uint32_t)kFogLightGroups, 1, 1);
+            if (ctx->counting) hipLaunchKernelGGL(k_fog_noise_light<true>, lg, dim3(256), 0, fs, fa);
+            else hipLaunchKernelGGL(k_fog_noise_light<false>, lg, dim3(256), 0, fs, fa);
+        } else {
+            // (the side stream has the shadow maps: it rendered them)
+            const dim3 mg((uint32_t)((npx + 63) / 64), 1, 1);
+            if (ctx->counting) hipLaunchKernelGGL(k_fog_march<true>, mg, dim3(64), 0, fs, fa);
+            else hipLaunchKernelGGL(k_fog_march<false>, mg, dim3(64), 0, fs, fa);
+            if (prof) { WR_HIP(hipEventRecord(ev[9], fs)); WR_HIP(hipEventRecord(ev[10], fs)); }
+        }
     } else if (prof) {
         WR_HIP(hipEventRecord(ev[6], fs));
         WR_HIP(hipEventRecord(ev[9], fs));
@@ -770,7 +811,8 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
     // main stream: fog colours over the finished geometry colour
     WR_HIP(hipStreamWaitEvent(ms, f->ev_join, 0));
     if (fog_pass) {
-        if (ctx->counting) hipLaunchKernelGGL(k_fog_shade_blend<true>, dim3(2048), dim3(256), 0, ms, fa);
+        if (!latency_schedule) hipLaunchKernelGGL(k_fog_blend, dim3(2048), dim3(256), 0, ms, fa);
+        else if (ctx->counting) hipLaunchKernelGGL(k_fog_shade_blend<true>, dim3(2048), dim3(256), 0, ms, fa);
         else hipLaunchKernelGGL(k_fog_shade_blend<false>, dim3(2048), dim3(256), 0, ms, fa);
         if (ctx->counting) hipLaunchKernelGGL(k_fog_multi<true>, dim3(1024), dim3(64), 0, ms, fa);
         else hipLaunchKernelGGL(k_fog_multi<false>, dim3(1024), dim3(64), 0, ms, fa);
@@ -850,11 +892,22 @@ int wr_create(const WrConfig* config, WrContext** out_ctx) {
         for (int k = 0; k < WrContext::kEvFrames; ++k)
             for (int i = 0; i < WrContext::kEvPerFrame; ++i) WR_HIP(hipEventCreate(&ctx->ev[k][i]));
         ctx->nfr = (int)std::min<uint32_t>(std::max<uint32_t>(config->frames_in_flight, 1u), (uint32_t)WrContext::kMaxFrames);
+        // Profiling aid: WR_DEBUG_ONE_STREAM=1 puts all of a frame's kernels on one stream, so
+        // that a kernel trace shows every kernel's duration with the device to itself.
+        const char* os_env = getenv("WR_DEBUG_ONE_STREAM");
+        const bool one_stream = os_env && os_env[0] == '1';
         for (int k = 0; k < ctx->nfr; ++k) {
             FrameRes* f = &ctx->fr[k];
             WR_HIP(hipStreamCreateWithFlags(&f->ms, hipStreamNonBlocking));
-            WR_HIP(hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
-            WR_HIP(hipStreamCreateWithFlags(&f->fs, hipStreamNonBlocking));
+            if (one_stream) {
+                f->side = f->fs = f->ms;
+            } else if (os_env && os_env[0] == '2') {  // fog work on the shadow stream
+                WR_HIP(hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
+                f->fs = f->side;
+            } else {
+                WR_HIP(hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
+                WR_HIP(hipStreamCreateWithFlags(&f->fs, hipStreamNonBlocking));
+            }
             hipEvent_t* evs[] = {&f->ev_fork, &f->ev_start, &f->ev_join, &f->ev_shadow_done, &f->ev_geom_done, &f->ev_done};
             for (hipEvent_t* e : evs) WR_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         }
@@ -900,8 +953,8 @@ void wr_destroy(WrContext* ctx) {
     for (FrameRes& f : ctx->fr) {
         dfree(f.d_shadow); dfree(f.d_noise_pool);
         if (f.ms) (void)hipStreamDestroy(f.ms);
-        if (f.side) (void)hipStreamDestroy(f.side);
-        if (f.fs) (void)hipStreamDestroy(f.fs);
+        if (f.side && f.side != f.ms) (void)hipStreamDestroy(f.side);
+        if (f.fs && f.fs != f.ms && f.fs != f.side) (void)hipStreamDestroy(f.fs);
         hipEvent_t evs[] = {f.ev_fork, f.ev_start, f.ev_join, f.ev_shadow_done, f.ev_geom_done, f.ev_done};
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     }
@@ -1342,6 +1395,12 @@ extern "C" int wr_dev_read(WrContext* ctx, int which, void* dst, size_t bytes) {
         case 3: src = ws.bin_items; have = (size_t)ws.items_cap * 4; break;
     }
     (void)sync_all(ctx);
+    if ((which >> 1) == 5) {
+        have = sizeof(unsigned long long) * 2 * 16 * 2;
+        if (bytes > have) bytes = have;
+        if (bytes && hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dbg_levels), bytes) != hipSuccess) return -1;
+        return (int)(have / 4);
+    }
     if ((which >> 1) == 4) {
         have = sizeof(unsigned long long) * 3 * 40000;
         if (bytes > have) bytes = have;

@@ -90,11 +90,22 @@ inline void mat4_mul_mat4(const float* a, const float* b, float* out) {  // out 
 // same bits.  On the device both polynomials are evaluated and one is selected (two dependent
 // chains that fill each other's latency; a branch would diverge on every hash).
 constexpr float kSinRange = 1073741824.0f;
-template <bool GUARD>
+// GUARD selects one of three forms that return the same bits wherever they are allowed:
+//   kSinGuarded  any argument;
+//   kSinInt      |x| < 2^30 promised by the caller: no range test;
+//   kSinFast     |x| <= kSinFastRange promised by the caller: the octant arithmetic stays in
+//                floating point.  h = j/2 = floor(|x| * 4/pi * 0.5 + 0.5) (the sum is exact
+//                while the product is below 2^24), r = |x| - h * (pi/2 in three parts) (the
+//                same products and roundings, the constants doubled), polynomial from the
+//                parity of h, sign from its second bit.  Three instructions fewer per hash;
+//                compared with kSinGuarded on every float of the range by the CPU tests.
+constexpr int kSinInt = 0, kSinGuarded = 1, kSinFast = 2;
+constexpr float kSinFastRange = 13176794.0f;  // 2^24 / (4/pi), rounded down
+template <int GUARD>
 WR_HD float wr_sin_t(float x) {
     float ax = fabsf(x);
     uint32_t sign = f2u(x) & 0x80000000u;
-    if (GUARD) {
+    if (GUARD == kSinGuarded) {
         // Branch-free: an out-of-range (or NaN) argument is replaced by +0 on entry, for
         // which the arithmetic below yields +0.
         const bool in_range = ax < kSinRange;
@@ -102,12 +113,23 @@ WR_HD float wr_sin_t(float x) {
         sign = in_range ? sign : 0u;
     }
     const float y0 = ax * 1.27323954473516f;
-    int j = (int)y0;
-    j = (j + 1) & ~1;
-    const float y = (float)j;
-    float r = fmaf(y, -0.78515625f, ax);
-    r = fmaf(y, -2.4187564849853515625e-4f, r);
-    r = fmaf(y, -3.77489497744594108e-8f, r);
+    float r;
+    uint32_t half_octant;  // j / 2: bit 0 selects the polynomial, bit 1 flips the sign
+    if (GUARD == kSinFast) {
+        const float h = floorf(fmaf(y0, 0.5f, 0.5f));
+        half_octant = (uint32_t)(int)h;
+        r = fmaf(h, -1.5703125f, ax);
+        r = fmaf(h, -4.837512969970703125e-4f, r);
+        r = fmaf(h, -7.54978995489188216e-8f, r);
+    } else {
+        int j = (int)y0;
+        j = (j + 1) & ~1;
+        const float y = (float)j;
+        half_octant = (uint32_t)j >> 1;
+        r = fmaf(y, -0.78515625f, ax);
+        r = fmaf(y, -2.4187564849853515625e-4f, r);
+        r = fmaf(y, -3.77489497744594108e-8f, r);
+    }
     const float z = r * r;
     float ps = -1.9515295891e-4f;
     ps = fmaf(ps, z, 8.3321608736e-3f);
@@ -121,9 +143,8 @@ WR_HD float wr_sin_t(float x) {
     pc = pc * z;
     pc = fmaf(z, -0.5f, pc);
     pc = pc + 1.0f;
-    const float res = (j & 2) ? pc : ps;
-    // bit 2 of j moved to the sign position; xor with the argument's sign
-    return u2f(f2u(res) ^ sign ^ (((uint32_t)j << 29) & 0x80000000u));
+    const float res = (half_octant & 1u) ? pc : ps;
+    return u2f(f2u(res) ^ ((sign ^ (half_octant << 30)) & 0x80000000u));
 }
 WR_HD float wr_sin(float x) { return wr_sin_t<true>(x); }
 
@@ -624,7 +645,7 @@ WR_HD float hash_fract(float s) {
 }
 // noise.wgsl:4 after the dot product: fract(sin(d) * 42123.45) * 2 - 1.  fr * 2 is exact,
 // so the fused form rounds once exactly where the two-step form rounds.
-template <bool GUARD>
+template <int GUARD>
 WR_HD float hash_from_dot(float d) {
     float s = wr_sin_t<GUARD>(d) * 42123.45f;
     return fmaf(hash_fract(s), 2.0f, -1.0f);
@@ -637,7 +658,7 @@ WR_HD float smooth01(float v) {
 // noise.wgsl:7-24.  The eight corner dot products (x*12.345 + y*67.89) + z*412.12 share
 // their six products and four x+y sums; every value is rounded exactly as when each
 // corner is evaluated on its own.
-template <bool GUARD>
+template <int GUARD>
 WR_HD float value_noise_t(V3 p) {
     float ux = floorf(p.x), uy = floorf(p.y), uz = floorf(p.z);
     float sx = smooth01(p.x - ux), sy = smooth01(p.y - uy), sz = smooth01(p.z - uz);
@@ -663,6 +684,9 @@ struct NoiseTable {
     const float* data;   // nullptr: level not tabled
     int lox, loy, loz;   // lattice coordinate of entry (0,0,0)
     int nx, ny, nz;
+#ifdef WR_DEV
+    int dbg_level, dbg_pad;  // level index, + 256 in the light-march kernel
+#endif
 };
 struct NoiseTables { NoiseTable level[16]; };  // [fbm index * 8 + octave]
 
@@ -670,7 +694,16 @@ WR_HD float lattice_hash(float ux, float uy, float uz) {  // rand(u) of noise.wg
     return hash_from_dot<true>((ux * 12.345f + uy * 67.89f) + uz * 412.12f);
 }
 
-template <bool GUARD>
+#if defined(WR_DEV)
+// Developer build: lane counts per noise level, [kernel kind][level][0 = table hit, 1 = direct].
+__device__ unsigned long long g_dbg_levels[2][16][2];
+#endif
+#if defined(WR_DEV) && defined(__HIP_DEVICE_COMPILE__)
+#define WR_DBG_LEVEL(level, direct) atomicAdd(&g_dbg_levels[(level) >> 8][(level) & 15][direct], 1ull)
+#else
+#define WR_DBG_LEVEL(level, direct) ((void)0)
+#endif
+template <int GUARD>
 WR_HD float value_noise_tab(V3 p, const NoiseTable& t) {
     float ux = floorf(p.x), uy = floorf(p.y), uz = floorf(p.z);
     // |u| < 2^24 here (the caller bounds |p|), so the conversions are exact
@@ -682,8 +715,14 @@ WR_HD float value_noise_tab(V3 p, const NoiseTable& t) {
         const size_t sy_ = (size_t)t.nx, sz_ = (size_t)t.nx * t.ny;
         float a = q[0], b = q[1], c = q[sy_], d = q[sy_ + 1];
         float e = q[sz_], f = q[sz_ + 1], g = q[sz_ + sy_], h = q[sz_ + sy_ + 1];
+#ifdef WR_DEV
+        WR_DBG_LEVEL(t.dbg_level, 0);
+#endif
         return mixf(mixf(mixf(a, b, sx), mixf(c, d, sx), sy), mixf(mixf(e, f, sx), mixf(g, h, sx), sy), sz);
     }
+#ifdef WR_DEV
+    WR_DBG_LEVEL(t.dbg_level, 1);
+#endif
     return value_noise_t<GUARD>(p);
 }
 
@@ -705,7 +744,7 @@ WR_HD bool fbm_decided(float ret, int i) {
     return dec;
 #endif
 }
-template <bool GUARD>
+template <int GUARD>
 WR_HD float fbm_t(V3 p) {
     float weight = 0.5f, ret = 0.0f;
     V3 q = p;
@@ -717,7 +756,7 @@ WR_HD float fbm_t(V3 p) {
     }
     return saturatef(ret);
 }
-template <bool GUARD>
+template <int GUARD>
 WR_HD float fbm_tab_t(V3 p, const NoiseTable* tabs) {
     float weight = 0.5f, ret = 0.0f;
     V3 q = p;
@@ -731,17 +770,29 @@ WR_HD float fbm_tab_t(V3 p, const NoiseTable* tabs) {
 }
 // noise.wgsl:26-40.  The last octave samples p*128 and every hash argument is at most
 // (|q|+1) * (12.345 + 67.89 + 412.12) (1 + 3*2^-24); for |p| < 16000 that stays below 2^30,
-// the sine's range guard can never fire and the unguarded instantiation is used.  The same
-// bound keeps the float -> int conversions that index the hash tables exact
+// the sine's range guard can never fire and an unguarded instantiation is used; for
+// |p| < 200 it stays below kSinFastRange (12604801 < 13176794) and the fast form serves.  The
+// first bound also keeps the float -> int conversions that index the hash tables exact
 // (|p| * 128 + 1 < 2^24).
-constexpr float kFbmUnguarded = 16000.0f;
+constexpr float kFbmUnguarded = 16000.0f, kFbmFast = 200.0f;
+WR_HD int fbm_sin_tier(V3 p) {  // NaN falls through to the guarded form
+#ifndef WR_DEV_NO_FAST_SINE
+    if (fabsf(p.x) < kFbmFast && fabsf(p.y) < kFbmFast && fabsf(p.z) < kFbmFast) return kSinFast;
+#endif
+    if (fabsf(p.x) < kFbmUnguarded && fabsf(p.y) < kFbmUnguarded && fabsf(p.z) < kFbmUnguarded) return kSinInt;
+    return kSinGuarded;
+}
 WR_HD float fbm(V3 p) {
-    if (fabsf(p.x) < kFbmUnguarded && fabsf(p.y) < kFbmUnguarded && fabsf(p.z) < kFbmUnguarded) return fbm_t<false>(p);  // false for NaN
-    return fbm_t<true>(p);
+    const int tier = fbm_sin_tier(p);
+    if (tier == kSinFast) return fbm_t<kSinFast>(p);
+    if (tier == kSinInt) return fbm_t<kSinInt>(p);
+    return fbm_t<kSinGuarded>(p);
 }
 WR_HD float fbm_tab(V3 p, const NoiseTable* tabs) {
-    if (fabsf(p.x) < kFbmUnguarded && fabsf(p.y) < kFbmUnguarded && fabsf(p.z) < kFbmUnguarded) return fbm_tab_t<false>(p, tabs);
-    return fbm_t<true>(p);
+    const int tier = fbm_sin_tier(p);
+    if (tier == kSinFast) return fbm_tab_t<kSinFast>(p, tabs);
+    if (tier == kSinInt) return fbm_tab_t<kSinInt>(p, tabs);
+    return fbm_t<kSinGuarded>(p);
 }
 // fog.wgsl:48-62
 WR_HD float fog_noise(const FrameConsts& fc, V3 pos) {

@@ -26,6 +26,18 @@
 
 namespace wr {
 
+// Issue priority of a wavefront among those resident on its SIMD.  Every kernel but the two
+// noise kernels of the fog march is short and waits on memory or atomics most of the time; the
+// noise kernels keep every wave slot of the chip issuing VALU instructions for most of a frame.
+// When they share a SIMD, a round-robin issue order makes each instruction of the short kernel
+// wait for all the marching waves' turns, which stretches it several times over while the march
+// gains nothing.  With the raised priority the short kernels issue whenever they are ready and
+// the march fills the cycles in between.
+#ifndef WR_LATENCY_PRIORITY
+#define WR_LATENCY_PRIORITY 3
+#endif
+__device__ inline void latency_bound_kernel() { __builtin_amdgcn_s_setprio(WR_LATENCY_PRIORITY); }
+
 struct RasterWS {
     Rec* recs;            // [layers][slots + ovf_cap]
     uint2* bb;            // [layers][slots + ovf_cap] pixel bounding box of each record, or (kBBInvalid, kBB*)
@@ -64,6 +76,7 @@ struct VertexOut {       // VertexOutput of globals.wgsl:55-62, packed in four f
 
 // pbr.wgsl:8-46
 __global__ __launch_bounds__(256) void k_vs_geometry(VertexIn in, VertexOut out, FrameConsts fc) {
+    latency_bound_kernel();
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= in.nv) return;
     float4 p = in.pos[i], n = in.nrm[i], t = in.tan[i], b = in.bit[i];
@@ -85,6 +98,7 @@ __global__ __launch_bounds__(256) void k_vs_geometry(VertexIn in, VertexOut out,
 
 // depth.wgsl:3-17, all six light_matrix_index values in one launch (grid.y = face)
 __global__ __launch_bounds__(256) void k_vs_shadow(const float4* pos, uint32_t nv, float4* clip, FrameConsts fc) {
+    latency_bound_kernel();
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nv) return;
     uint32_t face = blockIdx.y;
@@ -320,6 +334,7 @@ __device__ inline SetupTarget setup_target(const RasterWS& ws, uint32_t layer, i
 template <bool SHADOW>
 __global__ __launch_bounds__(256) void k_setup(const float4* clip, uint32_t nv, const uint32_t* idx, uint32_t ntris,
                                                RasterWS ws, int W, int H, int tile_rank, int tile_world) {
+    latency_bound_kernel();
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const bool have = t < ntris;
     uint32_t layer = blockIdx.y;
@@ -343,6 +358,7 @@ __global__ __launch_bounds__(256) void k_setup(const float4* clip, uint32_t nv, 
 template <bool SHADOW>
 __global__ __launch_bounds__(64) void k_setup_clip(const float4* clip, uint32_t nv, const uint32_t* idx, RasterWS ws, int W, int H,
                                                    int tile_rank, int tile_world) {
+    latency_bound_kernel();
     const uint32_t layer = blockIdx.y;
     const uint32_t n = min(ws.clip_count[layer], ws.slots);
     const float4* cl = clip + (size_t)layer * nv;
@@ -363,6 +379,7 @@ __global__ __launch_bounds__(64) void k_setup_clip(const float4* clip, uint32_t 
 // into its own record array.  enabled == 0 only invalidates the slots.
 __global__ void k_setup_small(const float4* pos, const uint32_t* idx, uint32_t ntris, int mode, int enabled,
                               uint32_t slot_base, RasterWS ws, FrameConsts fc) {
+    latency_bound_kernel();
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const bool have = t < ntris && enabled;
     if (t < ntris && !enabled) {
@@ -388,6 +405,7 @@ __global__ void k_setup_small(const float4* pos, const uint32_t* idx, uint32_t n
 // per record slot, reading only the 8-byte bounding boxes; records inside one bin (almost
 // all) are appended with wave-aggregated atomics.
 __global__ __launch_bounds__(256) void k_bin_fill(RasterWS ws, int tile_rank, int tile_world) {
+    latency_bound_kernel();
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t layer = blockIdx.y;
     uint32_t ovf = ws.ovf_count[layer];
@@ -414,6 +432,7 @@ __global__ __launch_bounds__(256) void k_bin_fill(RasterWS ws, int tile_rank, in
 // Exclusive prefix sum of the bin counts (one workgroup; n is a few thousand to a few ten thousand).
 constexpr uint32_t kScanThreads = 256;  // small on purpose: has to find room next to long-running kernels of other frames
 __global__ __launch_bounds__(kScanThreads) void k_scan(RasterWS ws) {
+    latency_bound_kernel();
     __shared__ uint32_t part[kScanThreads];
     uint32_t n = (uint32_t)(ws.bins_x * ws.bins_y * ws.layers);
     uint32_t tid = threadIdx.x;
@@ -524,6 +543,7 @@ __device__ unsigned long long g_dbg_cycles[3 * 40000];
 template <int MODE, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, uint32_t* vis, float* depth,
                                                     int tile_rank, int tile_world, LayerSink ls) {
+    latency_bound_kernel();
     constexpr int kRasterThreads = THREADS;
     __shared__ unsigned long long tile[MODE == kRasterShadow ? 1 : kBin * kBin];
     __shared__ uint32_t tile32[MODE == kRasterColor ? 1 : kBin * kBin];  // layers: fragments appended so far
@@ -847,6 +867,7 @@ template <bool COUNT>
 // five): shading waits on dependent fetches for half of a wavefront's life, and the sixth
 // resident wavefront shortens the launch by 4 %; seven or eight would spill.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_shade(ShadeArgs a) {
+    latency_bound_kernel();
     __shared__ uint32_t s_cnt, s_base;
     __shared__ float s_tab[768];
     // 16x16 pixels per workgroup, each wavefront an 8x8 block
@@ -901,6 +922,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 // it) become items for k_shade_frags.  Pixels covered by more than kReplayK fragments, or
 // left without room in the item buffer, are queued for k_replay_slow.
 __global__ __launch_bounds__(256) void k_resolve(ShadeArgs a) {
+    latency_bound_kernel();
     __shared__ uint32_t cid[kReplayK][256];
     __shared__ float cz[kReplayK][256];
     __shared__ uint32_t s_cnt, s_base;
@@ -963,6 +985,7 @@ __global__ __launch_bounds__(256) void k_resolve(ShadeArgs a) {
 // Ordered blending of the pixels k_resolve queued: the general, slow method.
 template <bool COUNT>
 __global__ __launch_bounds__(64) void k_replay_slow(ShadeArgs a) {
+    latency_bound_kernel();
     const BlendWS& bw = a.bw;
     const uint32_t n = min(bw.counts[2], bw.cap);
     if (blockIdx.x * 64u >= n) return;
@@ -976,6 +999,7 @@ __global__ __launch_bounds__(64) void k_replay_slow(ShadeArgs a) {
 // Ordered blending, step 3: one thread per fragment item runs pbr.wgsl's fs_main (the light
 // marker, drawn with REPLACE, has a constant colour: light_debug.wgsl:23-26).
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_shade_frags(ShadeArgs a) {
+    latency_bound_kernel();
     __shared__ float s_tab[768];
     const BlendWS& bw = a.bw;
     if (blockIdx.x * 64u >= min(bw.counts[1], bw.frag_cap)) return;
@@ -1005,6 +1029,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
 // order (geometry: SrcAlpha/OneMinusSrcAlpha, state.rs:465-467; light marker: REPLACE,
 // state.rs:480-482).
 __global__ __launch_bounds__(256) void k_blend(ShadeArgs a) {
+    latency_bound_kernel();
     __shared__ float s_tab[768];
     const BlendWS& bw = a.bw;
     const uint32_t nslots = min(bw.counts[0], bw.cap);
@@ -1042,7 +1067,8 @@ struct FogArgs {
     NoiseTables tables_noise;  // hash tables of the low octaves (k_fog_tables)
     float* noise_view;     // [kFogMaxSteps][cap] fog_noise of view-march step s of item k at s * cap + k
     float* noise_light;    // [kFogLightMaxSteps][cap] the same for the light march, indexed by position in the lit list
-    float4* item_res;      // [cap] view march of an item: density, depth, in_light, position in the lit list (bits)
+    float4* item_res;      // [cap] view march of an item: density, depth, in_light, position in the lit list (bits);
+                           // with k_fog_march: the item's fog colour
     uint32_t* lit_count;   // items whose fog point is lit (they need the light march)
     uint32_t* lit_item;    // [cap] their item indices
     uint32_t cap;          // W*H
@@ -1096,6 +1122,7 @@ static_assert(sizeof(StagedRec) == 88, "StagedRec layout");
 constexpr int kFogBlock = 32;
 template <bool COUNT>
 __global__ __launch_bounds__(1024) void k_fog_setup(FogArgs a) {
+    latency_bound_kernel();
     __shared__ StagedRec srec[256];
     __shared__ uint32_t s_m, s_cnt, s_base;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1194,6 +1221,7 @@ __global__ __launch_bounds__(1024) void k_fog_setup(FogArgs a) {
 // the geometry colour is final.
 template <bool COUNT>
 __global__ __launch_bounds__(64) void k_fog_multi(FogArgs a) {
+    latency_bound_kernel();
     const uint32_t n = *a.multi_count;
     if (blockIdx.x * 64u >= n) return;
     for (uint32_t k = blockIdx.x * 64u + threadIdx.x; k < n; k += gridDim.x * 64u) {
@@ -1251,6 +1279,7 @@ __host__ inline void plan_table_level(TablePlan& plan, int l, int nx, int ny, in
     plan.wg_begin[l + 1] = plan.wg_begin[l] + plan.xchunks[l] * plan.ychunks[l] * (uint32_t)nz;
 }
 __global__ __launch_bounds__(256) void k_fog_tables(NoiseTables nt, TablePlan plan) {
+    latency_bound_kernel();
     const uint32_t b = blockIdx.x;
     int level = 0;
     while (level < 15 && b >= plan.wg_begin[level + 1]) ++level;
@@ -1283,37 +1312,55 @@ __global__ __launch_bounds__(256) void k_fog_tables(NoiseTables nt, TablePlan pl
 //   k_fog_noise_light  fog_noise of the light-march steps of lit fog points
 //   k_fog_shade_blend  occlusion sums, fog colour, blend over the finished geometry colour
 #ifndef WR_FOG_STEP_GROUP
-#define WR_FOG_STEP_GROUP 5
+#define WR_FOG_STEP_GROUP 3
 #endif
 constexpr int kFogStepGroup = WR_FOG_STEP_GROUP;  // march steps one wavefront evaluates for its 64 items
+constexpr int kFogViewGroups = (kFogMaxSteps + kFogStepGroup - 1) / kFogStepGroup;
+constexpr int kFogLightGroups = (kFogLightMaxSteps + kFogStepGroup - 1) / kFogStepGroup;
 
 __device__ inline V3 fog_item_dir(const FrameConsts& fc, V3 origin) {  // fog.wgsl:127
     return normalize3(origin - v3(fc.cam_pos[0], fc.cam_pos[1], fc.cam_pos[2]));
 }
 
-// grid.x: 256 items per workgroup (each wavefront on its own), grid.y: group of steps
+// One wavefront: the noise of up to kFogStepGroup march steps of 64 consecutive items.
+// Positions are origin + dir * march_step_depth(step_size, step); `out` points at the lane's
+// column of the [step][cap] noise array.
+template <bool COUNT>
+__device__ inline void fog_noise_steps(const FogArgs& a, bool live, V3 origin, V3 dir, float max_depth, float step_size,
+                                       int max_steps, int s0, float* out, unsigned long long* counter) {
+#pragma unroll 1
+    for (int s = s0; s < s0 + kFogStepGroup && s < max_steps; ++s) {
+        const float depth = march_step_depth(step_size, s);
+        const bool act = live && !(depth >= max_depth);  // the march's exit test, fog.wgsl:70-72
+        if (!__any(act ? 1 : 0)) break;                  // depth only grows: no later step is active either
+        if (act) out[(size_t)s * a.cap] = fog_noise_tab(a.fc, a.tables_noise, origin + dir * depth);
+        if (COUNT && act) atomicAdd(counter, 1ull);
+    }
+}
+
+// The number of items is only known on the device, so the grid is sized for the worst case
+// (every pixel an item).  Workgroup w of the one-dimensional grid takes 256 items (each
+// wavefront on its own) and one group of steps: w = group * ceil(n / 256) + block, so the
+// workgroups that have work are the first ones dispatched and the surplus ones, which exit at
+// once, come after all of them instead of taking wave slots in between.
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_fog_noise_view(FogArgs a) {
     const uint32_t n = *a.item_count;
-    if ((blockIdx.x * 256u + (threadIdx.x & ~63u)) >= n) return;
-    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t blocks = (n + 255u) / 256u;
+    if (blockIdx.x >= blocks * (uint32_t)kFogViewGroups) return;
+    const uint32_t group = blockIdx.x / blocks, block = blockIdx.x % blocks;
+    if ((block * 256u + (threadIdx.x & ~63u)) >= n) return;
+    const uint32_t k = block * 256u + threadIdx.x;
     const bool live = k < n;
     const float4 ray = live ? a.item_ray[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const V3 origin = v3(ray.x, ray.y, ray.z);
-    const V3 dir = fog_item_dir(a.fc, origin);
-    const int s0 = (int)blockIdx.y * kFogStepGroup;
-#pragma unroll 1
-    for (int s = s0; s < s0 + kFogStepGroup && s < kFogMaxSteps; ++s) {
-        const float depth = march_step_depth(kFogStepSize, s);
-        const bool act = live && !(depth >= ray.w);  // the march's exit test, fog.wgsl:70-72
-        if (!__any(act ? 1 : 0)) break;              // depth only grows: no later step is active either
-        if (act) a.noise_view[(size_t)s * a.cap + k] = fog_noise_tab(a.fc, a.tables_noise, origin + dir * depth);
-        if (COUNT && act) atomicAdd(&a.counters[5], 1ull);
-    }
+    fog_noise_steps<COUNT>(a, live, origin, fog_item_dir(a.fc, origin), ray.w, kFogStepSize, kFogMaxSteps,
+                           (int)group * kFogStepGroup, a.noise_view + k, &a.counters[5]);
 }
 
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_fog_view_resolve(FogArgs a) {
+    latency_bound_kernel();
     __shared__ uint32_t s_cnt, s_base;
     const uint32_t n = *a.item_count;
     if (blockIdx.x * 256u >= n) return;
@@ -1343,29 +1390,25 @@ __global__ __launch_bounds__(256) void k_fog_view_resolve(FogArgs a) {
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_fog_noise_light(FogArgs a) {
     const uint32_t n = *a.lit_count;
-    if ((blockIdx.x * 256u + (threadIdx.x & ~63u)) >= n) return;
-    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t blocks = (n + 255u) / 256u;
+    if (blockIdx.x >= blocks * (uint32_t)kFogLightGroups) return;
+    const uint32_t group = blockIdx.x / blocks, block = blockIdx.x % blocks;
+    if ((block * 256u + (threadIdx.x & ~63u)) >= n) return;
+    const uint32_t j = block * 256u + threadIdx.x;
     const bool live = j < n;
     const uint32_t k = live ? a.lit_item[j] : 0u;
     const float4 ray = a.item_ray[k];
     const float4 res = a.item_res[k];
     const V3 origin = v3(ray.x, ray.y, ray.z);
-    const V3 dir = fog_item_dir(a.fc, origin);
-    const LightRay lr = fog_light_ray(a.fc, origin + dir * res.y);
-    const int s0 = (int)blockIdx.y * kFogStepGroup;
-#pragma unroll 1
-    for (int s = s0; s < s0 + kFogStepGroup && s < kFogLightMaxSteps; ++s) {
-        const float depth = march_step_depth(kFogLightStepSize, s);
-        const bool act = live && !(depth >= lr.max_dist);
-        if (!__any(act ? 1 : 0)) break;
-        if (act) a.noise_light[(size_t)s * a.cap + j] = fog_noise_tab(a.fc, a.tables_noise, lr.origin + lr.dir * depth);
-        if (COUNT && act) atomicAdd(&a.counters[6], 1ull);
-    }
+    const LightRay lr = fog_light_ray(a.fc, origin + fog_item_dir(a.fc, origin) * res.y);
+    fog_noise_steps<COUNT>(a, live, lr.origin, lr.dir, lr.max_dist, kFogLightStepSize, kFogLightMaxSteps,
+                           (int)group * kFogStepGroup, a.noise_light + j, &a.counters[6]);
 }
 
 // Blends SrcAlpha / OneMinusSrcAlpha over the finished geometry colour (state.rs:501).
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_fog_shade_blend(FogArgs a) {
+    latency_bound_kernel();
     __shared__ float s_tab[768];
     const uint32_t n = *a.item_count;
     if (blockIdx.x * 256u >= n) return;
@@ -1393,11 +1436,45 @@ __global__ __launch_bounds__(256) void k_fog_shade_blend(FogArgs a) {
     }
 }
 
+// The marches of one work item in one piece (both marches of fog.wgsl, then the fog colour),
+// one wavefront per workgroup: the schedule for frames that overlap on the device.  A launch
+// of these long-running wavefronts thins out towards its end, which is where the short kernels
+// of the neighbouring frames find their wave slots; the evenly sized units of the kernels above
+// fill every slot to the end and suit a frame that has the device to itself.
+template <bool COUNT>
+__global__ __launch_bounds__(64) void k_fog_march(FogArgs a) {
+    const uint32_t k = blockIdx.x * 64u + threadIdx.x;
+    if (k >= *a.item_count) return;
+    const float4 ray = a.item_ray[k];
+    ShadowMap sm{a.shadow, a.fc.S};
+    uint32_t evals = 0;
+    V4 src = fog_march_shade(a.fc, sm, &a.tables_noise, v3(ray.x, ray.y, ray.z), ray.w, evals);
+    if (COUNT) atomicAdd(&a.counters[1], (unsigned long long)evals);
+    a.item_res[k] = make_float4(src.x, src.y, src.z, src.w);
+}
+
+// Blends the fog colours k_fog_march left in item_res over the finished geometry colour
+// (SrcAlpha / OneMinusSrcAlpha, state.rs:501).
+__global__ __launch_bounds__(256) void k_fog_blend(FogArgs a) {
+    latency_bound_kernel();
+    __shared__ float s_tab[768];
+    const uint32_t n = *a.item_count;
+    if (blockIdx.x * 256u >= n) return;
+    stage_color_tables(s_tab, a.tables);
+    ColorTables ct{s_tab};
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n; k += gridDim.x * 256u) {
+        const uint32_t pi = a.item_pixel[k];
+        const float4 c = a.item_res[k];
+        a.color[pi] = blend_pack(ct, a.color[pi], V4{c.x, c.y, c.z, c.w}, true);
+    }
+}
+
 // ------------------------------------------------------------------ bin pack / scatter
 // Moves whole 64x64 colour bins between the frame and a packed [bin][64][64] buffer, for
 // gathering a frame whose bins were rendered on different devices.
 __global__ __launch_bounds__(256) void k_pack_bins(const uint32_t* color, uint32_t* packed, int W, int H, int bins_x,
                                                    int nbins, int rank, int world, int to_packed) {
+    latency_bound_kernel();
     int j = blockIdx.x;                 // j-th bin owned by `rank`
     int b = rank + j * world;
     if (b >= nbins) return;
@@ -1414,11 +1491,13 @@ __global__ __launch_bounds__(256) void k_pack_bins(const uint32_t* color, uint32
 // Zeroes the per-frame counter blocks of one stream in a single launch.
 struct ClearList { uint32_t* ptr[4]; uint32_t words[4]; };
 __global__ __launch_bounds__(256) void k_clear_words(ClearList c) {
+    latency_bound_kernel();
     for (int k = 0; k < 4; ++k)
         for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < c.words[k]; i += gridDim.x * 256u) c.ptr[k][i] = 0u;
 }
 
 __global__ void k_fill_f32(float* p, size_t n, float v) {
+    latency_bound_kernel();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
