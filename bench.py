@@ -38,28 +38,44 @@ if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 16:
 
 import numpy as np  # noqa: E402
 
-# Algorithmic f32 operations of one executed fog_noise evaluation inside ray_march
-# (fog.wgsl:64-85 + 48-62, noise.wgsl): 2 fbm x 8 octaves x (8 hashes of 31-34 ops incl. a
-# 21-op software sine, smoothstep, 7 mixes) + the march bookkeeping; a fused multiply-add
-# counts as 2: sine = quotient 3 + reduction 6 + z 1 + polynomial 8 + r*z 1 + last step 2 = 21;
-# rand = dot 5 + sine 21 + 5 = 31 (+3 for the corner offset on 7 of 8 corners); value_noise =
-# 6 + smoothstep 27 + hashes 31 + 7*34 + 7 mixes * 4 = 330; fbm = 8 * (330 + 6) + 2 = 2690;
-# fog_noise = 2 * 2690 + 58 + 4 = 5442; march bookkeeping 12.
-FLOP_PER_FOG_NOISE_EVAL = 5454
+# Algorithmic f32 operations of one fog_noise evaluation inside ray_march (fog.wgsl:64-85 +
+# 48-62, noise.wgsl), a fused multiply-add counted as 2.  Sine (Cephes scheme, one of its two
+# polynomials per call): octant 4 (multiply, truncate, round up to even, convert) + reduction 6
+# + z 1 + polynomial 8 (sine 7, cosine 9) = 19; rand = dot 5 + sine 19 + hash 5 = 29 (+3 for
+# the corner offset on 7 of 8 corners); value_noise = floor/fract 6 + smoothstep 27 + hashes
+# 29 + 7*32 + 7 mixes * 4 = 314; fbm = 8 * (314 + 6) + 2 = 2562; fog_noise = 2 * 2562 + 62 =
+# 5186; march bookkeeping 12.
+FLOP_PER_FOG_NOISE_EVAL = 5198
 PEAK_FP32_TFLOPS = 157.3   # MI355X f32 vector peak = dense f32 matrix peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
-# HBM bytes of one k_fog_march launch on the default frame, from the rocprofv3 PMC passes kept
-# in profiles/ (FETCH_SIZE doubled as the gfx950 note prescribes, plus WRITE_SIZE); None until
-# such a pass has been recorded for the current kernel.  (Algorithmic bytes of a launch: 20 B
-# read + 16 B written per work item = 24 MB; the rest is the 86 MB of noise tables and the shadow
-# map taps.)
-FOG_MARCH_HBM_BYTES = (2 * 27180 + 10420) * 1024  # profiles/r01_v7_pmc_hbm.txt
-# What the kernel executes for the default frame (the algorithmic count above prices octaves the
-# kernel reads from its tables or proves irrelevant as if they were evaluated): wave-level VALU
-# instructions of one launch, profiles/r01_v7_pmc_sq.txt, against the issue ceiling measured by
-# scripts/dev_ifetch_bench.hip (1.04 wave-instructions per ns and SIMD, 1024 SIMDs).
-FOG_MARCH_VALU_WAVE_INSTRUCTIONS = 4.175e8
-VALU_ISSUE_CEILING_PER_NS = 1.04 * 1024
+# VALU issue peak: one wave64 instruction per 2 cycles and SIMD (MI355X_MICROARCH.md, v_fma_f32
+# row), 1024 SIMDs, 2.4 GHz.  (scripts/dev_ifetch_bench.hip measures 1.04 per ns and SIMD.)
+VALU_ISSUE_PEAK_PER_NS = 1024 * 2.4 / 2.0
+PROFILE_JSON = os.path.join(ROOT, "profiles", "r02_counters.json")
+
+
+def source_hash():
+    """Hash of the sources libwr_hip.so is built from: ties a counter profile to a build."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "wgpu-renderer_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip", ".cpp")) or name == "Makefile":
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_profile(schedule):
+    """Per-kernel counters of profiles/r02_counters.json for the fog schedule in use ("1": one
+    frame in flight, "4": frames overlapping), or (None, reason) if the file is missing or was
+    taken on other sources."""
+    if not os.path.exists(PROFILE_JSON):
+        return None, "no counter profile committed"
+    prof = json.load(open(PROFILE_JSON))
+    if prof.get("source_hash") != source_hash():
+        return None, f"counter profile {prof.get('source_hash')} is of other kernel sources than this build ({source_hash()})"
+    return prof["schedules"].get(schedule, {}), None
 
 
 def build_scene(args):
@@ -206,6 +222,7 @@ def main():
     step(0)
     st = r.stats()
     fog_frags, noise_evals, shaded = int(st.fog_fragments), int(st.fog_noise_evals), int(st.shaded_fragments)
+    evals_view, evals_light = int(st.fog_noise_evals_view), int(st.fog_noise_evals_light)
     replay_px, replay_slow = int(st.replay_pixels), int(st.replay_slow_pixels)
     bin_items = (int(st.geometry_bin_items), int(st.shadow_bin_items))
     r.set_counting(False)
@@ -228,20 +245,30 @@ def main():
     st = r.stats()
     r.set_profiling(False)
 
-    # The same kernel with one frame at a time (its launches then overlap only this frame's
-    # shading kernels), outside the timed region: how fast the march runs when it does not
-    # share the device with the marches of the neighbouring frames.
-    march_alone_ms = None
+    # One frame at a time (the reference's own cadence, state.rs:678-806), outside the timed
+    # region: frame rate and the dominant kernel of that schedule.
+    one_frame = None
     if rank == 0 and args.workload == "frame" and in_flight > 1 and not args.skip_march_alone:
         r1 = abi.Renderer(W, H, S, device=local_rank, frames_in_flight=1)
         r1.upload_scene(sc)
-        for i in range(3):
+        r1.set_counting(True)
+        r1.render_frame(cam, light, glob, passes)
+        s1 = r1.stats()
+        ev1 = int(s1.fog_noise_evals_view)
+        r1.set_counting(False)
+        for i in range(5):
             r1.render_frame(cam, light, glob, passes)
         r1.sync()
-        r1.set_profiling(True)
+        t1 = time.perf_counter()
+        for i in range(40):
+            r1.render_frame(cam, light, glob, passes)
+        r1.sync()
+        dt1 = (time.perf_counter() - t1) / 40
+        r1.set_profiling(True)  # (the stage events cost a few per cent of a lone frame)
         for i in range(20):
             r1.render_frame(cam, light, glob, passes)
-        march_alone_ms = float(r1.stats().ms_fog_march)
+        s1 = r1.stats()
+        one_frame = {"frames_per_s": 1.0 / dt1, "view_ms": float(s1.ms_fog_march), "light_ms": float(s1.ms_fog_light_march), "evals_view": ev1}
         r1.close()
 
     frames_per_step = 1 if args.workload != "tiles4k" else 1.0 / world  # tiles: all ranks share one frame
@@ -252,33 +279,60 @@ def main():
                      and args.tex_size == 1024 and not args.sponza)
     out = None
     if rank == 0:
-        # the dominant kernel: k_fog_march, bracketed by its own HIP events on its stream
+        # The dominant kernel, bracketed by its own HIP events on its stream: with frames
+        # overlapping, k_fog_march (both marches of an item); with one frame in flight,
+        # k_fog_noise_view (the noise of the view-march steps).
+        latency_schedule = in_flight == 1
+        kernel = "k_fog_noise_view<false>" if latency_schedule else "k_fog_march<false>"
+        kernel_evals = evals_view if latency_schedule else noise_evals
         fog_s = st.ms_fog_march * 1e-3
-        fog_flops = FLOP_PER_FOG_NOISE_EVAL * noise_evals
+        fog_flops = FLOP_PER_FOG_NOISE_EVAL * kernel_evals
         frame_bytes = algorithmic_bytes(sc, W, H, S, shaded, fog_frags)
+        prof, why_not = load_profile("1" if latency_schedule else "4") if default_frame else (None, "counters are recorded for the default frame only")
+        executed = frame_valu = traffic = None
+        if prof:
+            pk = prof.get(kernel, {})
+            if pk.get("valu_wave_instructions") and fog_s > 0:
+                executed = {
+                    "valu_wave_instructions_per_launch": pk["valu_wave_instructions"],
+                    "issue_peak_wave_instructions_per_ns": VALU_ISSUE_PEAK_PER_NS,
+                    "issue_frac": pk["valu_wave_instructions"] / (fog_s * 1e9 * VALU_ISSUE_PEAK_PER_NS),
+                    "lanes_active": (pk["thread_cycles_valu"] / (pk["valu_wave_instructions"] * 64.0)) if pk.get("thread_cycles_valu") else None,
+                }
+            if pk.get("fetch_size_kb") is not None and pk.get("write_size_kb") is not None:
+                traffic = int((2 * pk["fetch_size_kb"] + pk["write_size_kb"]) * 1024)  # FETCH_SIZE doubled: gfx950 note of the guide
+            per_frame = sum(v["valu_wave_instructions"] or 0 for k, v in prof.items() if "<true>" not in k and "k_fill" not in k)
+            frame_valu = {
+                "wave_instructions_per_frame": per_frame,
+                "issue_frac": per_frame / (dt / args.steps * 1e9 * VALU_ISSUE_PEAK_PER_NS),
+                "note": "all kernels of one frame (counter pass, kernels serialised) against the frame time of the timed region",
+            }
         roofline = {
-            "kernel": "k_fog_march (fog.wgsl fragment stage: two ray marches through 2 x 8 octaves of value noise)",
+            "kernel": kernel + (" (fog.wgsl fragment stage: noise of the view-march steps, 2 x 8 octaves of value noise each)" if latency_schedule
+                                else " (fog.wgsl fragment stage: two ray marches through 2 x 8 octaves of value noise)"),
             "bound": "valu",
             "achieved": (fog_flops / fog_s) / 1e12 if fog_s > 0 else None,
             "peak": PEAK_FP32_TFLOPS,
             "unit": "TFLOP/s",
             "frac": ((fog_flops / fog_s) / 1e12) / PEAK_FP32_TFLOPS if fog_s > 0 else None,
-            "traffic": FOG_MARCH_HBM_BYTES if default_frame else None,
+            "traffic": traffic,
             "launch_ms": st.ms_fog_march,
             "launches_averaged": int(st.profiled_frames),
-            "concurrency": f"launches of up to {in_flight} frames in flight overlap each other and the other stages, which stretches "
-                           "each launch; one_frame_in_flight is the same kernel measured after the timed region with one frame at a time",
-            "one_frame_in_flight": None if not march_alone_ms else {
-                "launch_ms": march_alone_ms,
-                "achieved": fog_flops / (march_alone_ms * 1e-3) / 1e12,
-                "frac": fog_flops / (march_alone_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS},
             "flop_per_launch": fog_flops,
-            "executed": None if not default_frame else {
-                "valu_wave_instructions_per_launch": FOG_MARCH_VALU_WAVE_INSTRUCTIONS,
-                "issue_ceiling_wave_instructions_per_ns": VALU_ISSUE_CEILING_PER_NS,
-                "issue_frac": FOG_MARCH_VALU_WAVE_INSTRUCTIONS / (fog_s * 1e9 * VALU_ISSUE_CEILING_PER_NS) if fog_s > 0 else None,
-                "issue_frac_one_frame_in_flight": None if not march_alone_ms else
-                FOG_MARCH_VALU_WAVE_INSTRUCTIONS / (march_alone_ms * 1e6 * VALU_ISSUE_CEILING_PER_NS)},
+            "fog_noise_evals_per_launch": kernel_evals,
+            "algorithmic_note": "achieved prices every fog_noise evaluation at its algorithmic 5198 flop, also the octaves the kernel reads from "
+                                "per-frame hash tables or proves irrelevant; executed.issue_frac is what the kernel issues against the VALU issue peak",
+            "executed": executed,
+            "frame_valu": frame_valu,
+            "profile": {"file": os.path.relpath(PROFILE_JSON, ROOT), "source_hash": source_hash(), "used": bool(prof), "reason": why_not},
+            "concurrency": f"launches of up to {in_flight} frames in flight overlap each other and the other stages, which stretches each launch",
+            "one_frame_in_flight": None if not one_frame else {
+                "frames_per_s": one_frame["frames_per_s"],
+                "kernel": "k_fog_noise_view<false>",
+                "launch_ms": one_frame["view_ms"],
+                "light_march_launch_ms": one_frame["light_ms"],
+                "achieved": FLOP_PER_FOG_NOISE_EVAL * one_frame["evals_view"] / (one_frame["view_ms"] * 1e-3) / 1e12 if one_frame["view_ms"] > 0 else None,
+                "frac": FLOP_PER_FOG_NOISE_EVAL * one_frame["evals_view"] / (one_frame["view_ms"] * 1e-3) / 1e12 / PEAK_FP32_TFLOPS if one_frame["view_ms"] > 0 else None},
         }
         stage_ms = {"shadow": st.ms_shadow, "geometry": st.ms_geometry, "shade": st.ms_shade, "fog": st.ms_fog}
         hbm = {
@@ -329,6 +383,7 @@ def main():
             "stage_ms": stage_ms,
             "fog_fragments": fog_frags,
             "fog_noise_evals": noise_evals,
+            "fog_noise_evals_evaluated": {"view": evals_view, "light": evals_light},
             "shaded_fragments": shaded,
             "ordered_blend_pixels": replay_px,
             "ordered_blend_slow_pixels": replay_slow,
