@@ -82,13 +82,23 @@ def build_scene(args):
     import wgpu_renderer_amd  # noqa: F401
     from wgpu_renderer_amd import abi, scene
 
-    if args.sponza and os.path.exists(args.sponza):
+    if args.sponza:
+        if not os.path.exists(args.sponza):
+            raise SystemExit(f"--sponza {args.sponza}: no such file (res/models/Sponza.glb is not part of the reference checkout)")
         from wgpu_renderer_amd import gltf_loader
         model, textures = gltf_loader.load_glb(args.sponza)
+        # the same file through the library's own importer (the one a host without Python uses)
+        g = abi.Glb(path=args.sponza)
+        native = (g.mesh_count, g.material_count, g.texture_count)
+        g.close()
+        if native != (len(model.meshes), len(model.materials), len(textures)):
+            raise SystemExit(f"importers disagree on {args.sponza}: native {native}, python {(len(model.meshes), len(model.materials), len(textures))}")
         cube = scene.cube_model()
         sc = scene.Scene(textures, model, cube, scene.cube_model(),
                          abi.instance_raw(scene.REFERENCE_GEOMETRY_INSTANCE["position"]),
                          abi.instance_raw(scene.REFERENCE_FOG_INSTANCE["position"], (1, 0, 0, 0), scene.REFERENCE_FOG_INSTANCE["scale"]))
+        print(f"loaded {args.sponza}: V={model.vertex_count} I={3 * model.triangle_count} P={len(model.meshes)} M={len(model.materials)} "
+              f"textures={len(textures)}", file=sys.stderr, flush=True)
         return sc, os.path.basename(args.sponza)
     return scene.sponza_standin(detail=args.detail, tex_size=args.tex_size), "procedural Sponza stand-in (seed 0x5EED)"
 
@@ -375,6 +385,8 @@ def main():
                 "triangles": sc.geometry.triangle_count,
                 "vertices": sc.geometry.vertex_count,
                 "materials": len(sc.geometry.materials),
+                "primitives": len(sc.geometry.meshes),
+                "textures": len(sc.textures),
                 "texture_size": args.tex_size if "stand-in" in scene_name else None,
                 "parallelism": f"frame-parallel x{world}" if args.workload != "tiles4k" else f"screen-bin sharded x{world}",
                 "frames_in_flight": in_flight,

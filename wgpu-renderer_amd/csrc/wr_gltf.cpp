@@ -25,6 +25,8 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <utility>
 #include <vector>
@@ -55,7 +57,19 @@ struct JVal {
         const JVal* v = get(key);
         return (v && v->type == Num) ? v->num : dflt;
     }
-    long integer(const char* key, long dflt) const { return (long)number(key, (double)dflt); }
+    long integer(const char* key, long dflt) const {
+        const double d = number(key, (double)dflt);
+        // anything that is not an integer of moderate size reads as -1, which every caller rejects
+        if (!(d >= -1.0 && d <= 9.0e15) || d != (double)(long)d) return -1;
+        return (long)d;
+    }
+    // A size or offset: a non-negative integer below 2^53, else `ok` turns false.
+    size_t unsigned_integer(const char* key, size_t dflt, bool& ok) const {
+        const JVal* v = get(key);
+        if (!v) return dflt;
+        if (v->type != Num || !(v->num >= 0.0 && v->num <= 9.0e15) || v->num != (double)(unsigned long long)v->num) { ok = false; return 0; }
+        return (size_t)v->num;
+    }
     size_t size() const { return type == Arr ? arr.size() : 0; }
 };
 
@@ -304,13 +318,26 @@ bool get_accessor(const JVal& js, const std::vector<uint8_t>& bin, long index, A
     a.ncomp = t == "SCALAR" ? 1 : t == "VEC2" ? 2 : t == "VEC3" ? 3 : t == "VEC4" ? 4 : 0;
     const size_t cs = comp_size(a.comp);
     if (!cs || !a.ncomp) { err = "glb: unsupported accessor type"; return false; }
-    a.count = (size_t)acc.integer("count", 0);
+    bool ok = true;
+    a.count = acc.unsigned_integer("count", 0, ok);
     const JVal* nrm = acc.get("normalized");
     a.normalized = nrm && nrm->type == JVal::Bool && nrm->b;
-    const size_t start = (size_t)bv.integer("byteOffset", 0) + (size_t)acc.integer("byteOffset", 0);
-    a.stride = (size_t)bv.integer("byteStride", 0);
-    if (a.stride == 0) a.stride = cs * (size_t)a.ncomp;
-    if (a.count && start + a.stride * (a.count - 1) + cs * (size_t)a.ncomp > bin.size()) { err = "glb: accessor exceeds the buffer"; return false; }
+    const size_t view_off = bv.unsigned_integer("byteOffset", 0, ok), acc_off = acc.unsigned_integer("byteOffset", 0, ok);
+    const size_t view_len = bv.unsigned_integer("byteLength", 0, ok);
+    a.stride = bv.unsigned_integer("byteStride", 0, ok);
+    if (!ok) { err = "glb: accessor or buffer view with a negative, fractional or oversized number"; return false; }
+    const size_t elem = cs * (size_t)a.ncomp;
+    if (a.stride == 0) a.stride = elem;
+    if (a.stride < elem) { err = "glb: byteStride smaller than the element"; return false; }
+    // all comparisons by subtraction from known-good sizes: nothing here can wrap
+    if (view_off > bin.size() || view_len > bin.size() - view_off) { err = "glb: buffer view exceeds the buffer"; return false; }
+    if (a.count) {
+        if (acc_off > view_len || elem > view_len - acc_off || a.count - 1 > (view_len - acc_off - elem) / a.stride) {
+            err = "glb: accessor exceeds its buffer view";
+            return false;
+        }
+    }
+    const size_t start = view_off + acc_off;
     a.base = bin.data() + start;
     return true;
 }
@@ -424,8 +451,9 @@ int parse_glb(const uint8_t* data, size_t bytes, WrGlb& g, std::string& err) {
             long bvi = img.integer("bufferView", -1);
             if (bvi < 0 || !views || (size_t)bvi >= views->size()) { err = "glb: images must be embedded buffer views"; return WR_ERR_UNSUPPORTED; }
             const JVal& bv = views->arr[(size_t)bvi];
-            size_t o = (size_t)bv.integer("byteOffset", 0), len = (size_t)bv.integer("byteLength", 0);
-            if (o + len > bin.size()) { err = "glb: image exceeds the buffer"; return WR_ERR_INVALID_ARGUMENT; }
+            bool ok = true;
+            const size_t o = bv.unsigned_integer("byteOffset", 0, ok), len = bv.unsigned_integer("byteLength", 0, ok);
+            if (!ok || o > bin.size() || len > bin.size() - o) { err = "glb: image exceeds the buffer"; return WR_ERR_INVALID_ARGUMENT; }
             Image im;
             int rc;
             if (len >= 3 && bin[o] == 0xFF && bin[o + 1] == 0xD8) rc = wr_decode_jpeg(bin.data() + o, len, &im.w, &im.h, im.rgba, err);
@@ -485,12 +513,29 @@ extern "C" {
 int wr_glb_parse(const void* data, size_t bytes, WrGlb** out, char* err, size_t err_cap) {
     if (!data || !out) return WR_ERR_INVALID_ARGUMENT;
     *out = nullptr;
-    WrGlb* g = new WrGlb();
-    std::string e;
-    int rc = parse_glb((const uint8_t*)data, bytes, *g, e);
-    if (rc != WR_OK) { set_err(err, err_cap, e); delete g; return rc; }
-    *out = g;
-    return WR_OK;
+    // nothing may leave through the C boundary: allocation failures and anything else the
+    // parser or the decoders throw become status codes
+    WrGlb* g = nullptr;
+    try {
+        g = new WrGlb();
+        std::string e;
+        int rc = parse_glb((const uint8_t*)data, bytes, *g, e);
+        if (rc != WR_OK) { set_err(err, err_cap, e); delete g; return rc; }
+        *out = g;
+        return WR_OK;
+    } catch (const std::bad_alloc&) {
+        delete g;
+        set_err(err, err_cap, "glb: out of memory");
+        return WR_ERR_OUT_OF_MEMORY;
+    } catch (const std::exception& ex) {
+        delete g;
+        set_err(err, err_cap, std::string("glb: ") + ex.what());
+        return WR_ERR_INVALID_ARGUMENT;
+    } catch (...) {
+        delete g;
+        set_err(err, err_cap, "glb: unexpected failure");
+        return WR_ERR_INVALID_ARGUMENT;
+    }
 }
 
 int wr_glb_load_file(const char* path, WrGlb** out, char* err, size_t err_cap) {
@@ -499,9 +544,15 @@ int wr_glb_load_file(const char* path, WrGlb** out, char* err, size_t err_cap) {
     FILE* f = fopen(path, "rb");
     if (!f) { set_err(err, err_cap, std::string("cannot open ") + path); return WR_ERR_INVALID_ARGUMENT; }
     std::vector<uint8_t> buf;
-    uint8_t tmp[1 << 16];
-    size_t n;
-    while ((n = fread(tmp, 1, sizeof(tmp), f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+    try {
+        uint8_t tmp[1 << 16];
+        size_t n;
+        while ((n = fread(tmp, 1, sizeof(tmp), f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+    } catch (...) {
+        fclose(f);
+        set_err(err, err_cap, "glb: out of memory");
+        return WR_ERR_OUT_OF_MEMORY;
+    }
     fclose(f);
     return wr_glb_parse(buf.data(), buf.size(), out, err, err_cap);
 }
