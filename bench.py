@@ -12,8 +12,8 @@ ranks divided by the slowest rank's time.
 
 Other workloads (not the default line): --workload posebatch renders the 512-pose
 flythrough split contiguously over the ranks (wr_render_batch), --workload tiles4k renders
-3840x2160 with screen bins interleaved over the ranks and gathers them on rank 0 through
-torch.distributed (RCCL all_gather).
+3840x2160 with screen bins interleaved over the ranks and gathers them on rank 0 with
+wr_gather_bins (grouped RCCL send / recv queued behind the frame, no host synchronisation).
 
 res/models/Sponza.glb is not part of the reference checkout, so the scene is the procedural
 stand-in of wgpu_renderer_amd.scene (about 262k triangles, 25 materials, 1024^2 textures)
@@ -153,6 +153,8 @@ def main():
                     help="leave out the extra one-frame-in-flight pass after the timed region (for profiling runs)")
     ap.add_argument("--animate", action="store_true",
                     help="posebatch: t = time + k/60 for pose k (light, fog drift and shadow maps change every frame)")
+    ap.add_argument("--reuse-shadows", action="store_true",
+                    help="posebatch with a fixed light: render the shadow maps once and reuse them (wr_render_batch's shared-shadow mode)")
     ap.add_argument("--frames-in-flight", type=int, default=4, choices=[1, 2, 3, 4],
                     help="sets of frame buffers the library alternates between (WrConfig.frames_in_flight)")
     args = ap.parse_args()
@@ -195,12 +197,13 @@ def main():
         if world > 1:
             dist.barrier()
 
-    gather_buf = packed = None
+    comm = None
     if args.workload == "tiles4k" and world > 1:
-        from wgpu_renderer_amd import sharding
-        per = sharding.bins_per_rank(W, H, world)
-        packed = torch.zeros(per * 64 * 64, dtype=torch.int32, device="cuda")
-        gather_buf = torch.zeros(world * per * 64 * 64, dtype=torch.int32, device="cuda")
+        # RCCL communicator of the library's own (wr_comm_*): rank 0 makes the id, torch.distributed
+        # carries the 128 bytes, every rank joins on its device
+        box = [abi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm = abi.comm_create(box[0], rank, world, local_rank)
 
     poses = None
     if args.workload == "posebatch":
@@ -218,14 +221,17 @@ def main():
     def step(i):
         if args.workload == "posebatch":
             j = i % len(poses)
-            r.render_frame(poses[j], pose_light[j], pose_glob[j], passes)
+            if args.animate:
+                r.render_frame(poses[j], pose_light[j], pose_glob[j], passes)
+            elif not args.reuse_shadows:  # wr_render_batch over this rank's shard, every pass recomputed per pose
+                r.render_batch([poses[j]], light, glob, passes, shadows_every_frame=True)
+            elif i % 16 == 0:  # sixteen steps per call: the shadow maps of the fixed light are rendered once per call
+                r.render_batch([poses[(i + k) % len(poses)] for k in range(min(16, args.steps - i) if i < args.steps else 16)],
+                               light, glob, passes, shadows_every_frame=False)
         else:
             r.render_frame(cam, light, glob, passes)
-            if gather_buf is not None:
-                r.sync()
-                r.pack_owned_bins(packed.data_ptr())
-                r.sync()
-                dist.all_gather_into_tensor(gather_buf, packed)
+            if comm is not None:
+                r.gather_bins(comm, 0)  # queued behind the frame on the context's stream: no host sync
 
     # one counted frame (outside the timed region) for the algorithmic work of this frame
     r.set_counting(True)
@@ -379,8 +385,9 @@ def main():
                 "workload": {"frame": f"configs[2]: Sponza-class scene {W}x{H}, shadow map 6x{S}^2 + PCF, PBS, light marker, fog; "
                                       "reference default camera (-500,150,0) yaw 0, t=2.0; every pass recomputed each frame",
                              "posebatch": f"configs[4]: {args.poses}-pose flythrough at {W}x{H}, shadows+fog, poses split contiguously over ranks, "
-                                          + ("t = 2.0 + k/60 per pose" if args.animate else "t fixed") + ", every pass recomputed each frame",
-                             "tiles4k": "configs[3]: 3840x2160 shadows+fog, 64x64 bins interleaved over ranks, RCCL all_gather of colour bins"}[args.workload],
+                                          + ("t = 2.0 + k/60 per pose" if args.animate else "t fixed")
+                                          + (", shadow maps shared by 16 poses" if args.reuse_shadows and not args.animate else ", every pass recomputed each frame"),
+                             "tiles4k": "configs[3]: 3840x2160 shadows+fog, 64x64 bins interleaved over ranks, packed colour bins gathered on rank 0 by grouped RCCL send/recv (wr_gather_bins)"}[args.workload],
                 "scene": scene_name,
                 "triangles": sc.geometry.triangle_count,
                 "vertices": sc.geometry.vertex_count,
@@ -406,6 +413,8 @@ def main():
         }
         print(json.dumps(out), flush=True)
     r.close()
+    if comm is not None:
+        abi.comm_destroy(comm)
     if world > 1:
         dist.destroy_process_group()
 

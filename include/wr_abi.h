@@ -267,6 +267,49 @@ void* wr_color_device_ptr(WrContext* ctx);
 int wr_pack_owned_bins(WrContext* ctx, void* device_dst, uint32_t* out_bins);
 int wr_scatter_bins(WrContext* ctx, const void* device_src, uint32_t rank, uint32_t world);
 
+/* ---- gathering a bin-sharded frame (BASELINE configs[3]: one frame, its 64x64 bins dealt
+ * round-robin over the ranks).  No counterpart in the reference, which is single-GPU; the
+ * frame arriving complete on one device stands for its `surface_texture.present()`
+ * (state.rs:806).
+ *
+ * wr_gather_layout: rank `rank` of `world` owns bins rank, rank + world, ... of the row-major
+ * bin grid; `*owned` of them.  Every rank's packed bins occupy a slot of `*slot_bins` bins
+ * (ceil(bins / world)) in the root's receive area, rank r's slot at bin offset r * *slot_bins.
+ * Pure arithmetic: needs no device. */
+void wr_gather_layout(uint32_t width, uint32_t height, uint32_t world, uint32_t rank,
+                      uint32_t* owned, uint32_t* slot_bins);
+
+/* How packed bins travel between ranks.  `send` / `recv` move `bytes` of device memory to /
+ * from rank `peer`, ordered on the HIP stream `stream`; a group brackets the transfers of one
+ * gather like ncclGroupStart / ncclGroupEnd.  Each returns 0 on success.  The library calls
+ * them synchronously, on the caller's thread, inside wr_gather_bins_via only.  wr_gather_bins
+ * uses RCCL; tests bring a host-side stand-in. */
+typedef struct WrTransport {
+    void* user;
+    int (*group_start)(void* user);
+    int (*send)(void* user, const void* device_buf, size_t bytes, int peer, void* stream);
+    int (*recv)(void* user, void* device_buf, size_t bytes, int peer, void* stream);
+    int (*group_end)(void* user);
+} WrTransport;
+
+/* Collects the most recent frame of a bin-sharded set of contexts (WrConfig.tile_world > 1,
+ * one context per rank) on rank `root`: every other rank packs its bins and sends them, the
+ * root receives into its slots and writes the bins into its own colour target, which then
+ * holds the whole frame.  Everything is queued on the context's stream behind the frame:
+ * no host synchronisation between rendering, packing and the transfers.  Every rank of the
+ * frame must make the call. */
+int wr_gather_bins_via(WrContext* ctx, const WrTransport* transport, uint32_t root);
+/* The same over RCCL: `nccl_comm` is an ncclComm_t of `tile_world` ranks in which this
+ * context's rank is `tile_rank` (grouped ncclSend / ncclRecv straight to the root: one hop
+ * on the root's own xGMI link to each peer). */
+int wr_gather_bins(WrContext* ctx, void* nccl_comm, uint32_t root);
+/* RCCL communicator helpers for hosts that do not bind RCCL themselves (the library loads
+ * librccl.so.1 on first use): rank 0 makes an id, every rank gets the 128 bytes by the host's
+ * own means and creates its communicator on its context's device. */
+int wr_comm_unique_id(uint8_t id[128]);
+int wr_comm_create(const uint8_t id[128], uint32_t rank, uint32_t world, int32_t device, void** out_comm);
+int wr_comm_destroy(void* comm);
+
 int wr_set_profiling(WrContext* ctx, int enabled);
 /* enabled != 0 makes the next frames also count fragments / march steps with atomics
  * (slower; never enable it inside a timed region). */

@@ -526,6 +526,69 @@ def test_4k_bin_sharding_over_eight_contexts(full_scene):
     whole.close()
 
 
+def test_gather_bins_on_the_device_with_a_stand_in_transport(small_scene):
+    """wr_gather_bins_via, the code wr_gather_bins runs over RCCL, with three bin-sharded contexts
+    on this one device and a transport that copies device memory between them: the root ends up
+    with the frame one context renders alone.  (RCCL itself needs one device per rank; the box
+    has one.)"""
+    import ctypes as C
+    import torch
+    w, h, s = 1000, 520, 256
+    cam, light, glob = default_inputs(w, h)
+    whole = abi.Renderer(w, h, s)
+    whole.upload_scene(small_scene)
+    whole.render_frame(cam, light, glob, abi.PASS_ALL)
+    ref = whole.read_color()
+    whole.close()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    world, root = 3, 1
+    ranks = [abi.Renderer(w, h, s, tile_rank=r, tile_world=world) for r in range(world)]
+    sent, log = {}, []
+
+    def transport(rank):
+        def send(user, buf, nbytes, peer, stream):
+            sent[(rank, peer)] = (buf, nbytes)
+            log.append(("send", rank, peer, nbytes))
+            return 0
+
+        def recv(user, buf, nbytes, peer, stream):
+            src, n = sent[(peer, rank)]
+            log.append(("recv", rank, peer, nbytes))
+            if n != nbytes:
+                return 1
+            torch.cuda.synchronize()  # the sender's pack kernel ran on its own stream
+            return hip.hipMemcpy(buf, src, nbytes, 3)  # device to device
+
+        t = abi.Transport(None, abi.Transport.GROUP(lambda u: 0), abi.Transport.SEND(send), abi.Transport.RECV(recv),
+                          abi.Transport.GROUP(lambda u: 0))
+        return t
+
+    keep = []
+    for r in ranks:
+        r.upload_scene(small_scene)
+        r.render_frame(cam, light, glob, abi.PASS_ALL)
+    for k in [r for r in range(world) if r != root] + [root]:  # senders first: the stand-in has no queue of its own
+        t = transport(k)
+        keep.append(t)
+        ranks[k].gather_bins_via(t, root)
+        ranks[k].sync()
+    assert np.array_equal(ranks[root].read_color(), ref)
+    nb = ((w + 63) // 64) * ((h + 63) // 64)
+    assert sorted(x[3] for x in log if x[0] == "send") == sorted(len(range(r, nb, world)) * 64 * 64 * 4 for r in range(world) if r != root)
+    # a non-root rank still holds only its own bins
+    other = ranks[0].read_color()
+    assert not np.array_equal(other, ref)
+    with pytest.raises(abi.WrError):
+        ranks[0].gather_bins_via(keep[0], 5)  # root outside the world
+    for r in ranks:
+        r.close()
+    one = abi.Renderer(64, 64, 64)
+    with pytest.raises(abi.WrError):
+        one.gather_bins_via(keep[0], 0)  # not a bin-sharded context
+    one.close()
+
+
 def test_largest_target(tiny_scene):
     """7168 x 7168 is the largest target wr_create accepts (16-bit pixel coordinates in the
     set-up records, guard band of 8w); one more pixel is an argument error."""

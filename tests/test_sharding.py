@@ -92,3 +92,79 @@ def test_gloo_bin_gather_and_pose_split(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(results) == [(r, True) for r in range(world)]
+
+
+# ------------------------------------------------------------------ wr_gather_layout / wr_gather_bins_via
+def test_gather_layout_matches_the_round_robin_deal():
+    """The C ABI's layout function (what wr_gather_bins_via addresses the root's receive area
+    with) against the Python restatement, ragged sizes and worlds that do not divide the bins."""
+    from wgpu_renderer_amd import abi
+    for (w, h) in ((3840, 2160), (1920, 1080), (333, 207), (64, 64), (1, 1)):
+        for world in (1, 2, 3, 4, 7, 8):
+            slots = {abi.gather_layout(w, h, world, r)[1] for r in range(world)}
+            assert slots == {sharding.bins_per_rank(w, h, world)}
+            for r in range(world):
+                assert abi.gather_layout(w, h, world, r)[0] == len(sharding.owned_bins(w, h, r, world))
+    assert abi.gather_layout(64, 64, 4, 9) == (0, 1)  # a rank outside the world owns nothing
+
+
+def _gather_worker(rank, world, port, w, h, root, q):
+    """One rank of a gather to `root` with gloo send / recv standing in for the transport: every
+    rank packs its bins, the root receives each peer's bins at the slot wr_gather_layout names
+    and writes them into its frame, exactly the steps of wr_gather_bins_via."""
+    import torch
+    import torch.distributed as dist
+    from wgpu_renderer_amd import abi
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(7)
+        truth = rng.integers(0, 2 ** 31, (h, w), dtype=np.int64).astype(np.uint32)
+        mine = np.zeros_like(truth)
+        sharding.scatter_bins_host(mine, sharding.pack_bins_host(truth, rank, world), rank, world)  # only this rank's bins
+        owned, slot = abi.gather_layout(w, h, world, rank)
+        ok = True
+        if rank != root:
+            packed = sharding.pack_bins_host(mine, rank, world)[:owned]
+            if owned:
+                dist.send(torch.from_numpy(packed.astype(np.int32).copy()), dst=root)
+        else:
+            recv_area = np.zeros((world * slot, sharding.BIN, sharding.BIN), np.uint32)
+            for r in range(world):
+                if r == root:
+                    continue
+                owned_r = abi.gather_layout(w, h, world, r)[0]
+                if owned_r:
+                    buf = torch.zeros((owned_r, sharding.BIN, sharding.BIN), dtype=torch.int32)
+                    dist.recv(buf, src=r)
+                    recv_area[r * slot: r * slot + owned_r] = buf.numpy().astype(np.uint32)
+            frame = mine.copy()  # the root's own bins are in place
+            bx, by = sharding.bin_grid(w, h)
+            for b in range(bx * by):  # k_scatter_gathered: bin b is rank b % world's (b // world)-th
+                r, j = b % world, b // world
+                if r == root:
+                    continue
+                oy, ox = (b // bx) * sharding.BIN, (b % bx) * sharding.BIN
+                th, tw = min(sharding.BIN, h - oy), min(sharding.BIN, w - ox)
+                frame[oy:oy + th, ox:ox + tw] = recv_area[r * slot + j, :th, :tw]
+            ok = bool(np.array_equal(frame, truth))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,root", [(2, 0), (3, 2)])
+def test_gloo_gather_to_root_with_the_c_layout(world, root):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, 333, 207, root, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(r, True) for r in range(world)]

@@ -102,6 +102,14 @@ class FrameStats(C.Structure):
 assert C.sizeof(InstanceRaw) == 100 and C.sizeof(CameraUniform) == 224
 assert C.sizeof(LightUniform) == 416 and C.sizeof(GlobalUniforms) == 16
 
+class Transport(C.Structure):
+    """WrTransport: how packed bins travel between ranks (wr_gather_bins_via)."""
+    GROUP = C.CFUNCTYPE(C.c_int, C.c_void_p)
+    SEND = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+    RECV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+    _fields_ = [("user", C.c_void_p), ("group_start", GROUP), ("send", SEND), ("recv", RECV), ("group_end", GROUP)]
+
+
 # every symbol include/wr_abi.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = {
@@ -125,6 +133,12 @@ SYMBOLS = {
     "wr_color_device_ptr": (_P, [_P]),
     "wr_pack_owned_bins": (C.c_int, [_P, _P, C.POINTER(C.c_uint32)]),
     "wr_scatter_bins": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32]),
+    "wr_gather_layout": (None, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "wr_gather_bins_via": (C.c_int, [_P, _P, C.c_uint32]),
+    "wr_gather_bins": (C.c_int, [_P, _P, C.c_uint32]),
+    "wr_comm_unique_id": (C.c_int, [_P]),
+    "wr_comm_create": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_int32, C.POINTER(_P)]),
+    "wr_comm_destroy": (C.c_int, [_P]),
     "wr_glb_parse": (C.c_int, [_P, C.c_size_t, C.POINTER(_P), C.c_char_p, C.c_size_t]),
     "wr_glb_load_file": (C.c_int, [C.c_char_p, C.POINTER(_P), C.c_char_p, C.c_size_t]),
     "wr_glb_free": (None, [_P]),
@@ -210,6 +224,34 @@ def instance_raw(position, rotation_wxyz=(1.0, 0.0, 0.0, 0.0), scale=(1.0, 1.0, 
 
 def global_uniforms(time: float, use_shadowmaps: int) -> GlobalUniforms:
     return GlobalUniforms(float(time), 0, int(use_shadowmaps), 0)
+
+
+def gather_layout(width: int, height: int, world: int, rank: int):
+    """(bins owned by `rank`, bins per slot of the root's receive area): wr_gather_layout."""
+    owned, slot = C.c_uint32(), C.c_uint32()
+    load_library().wr_gather_layout(width, height, world, rank, C.byref(owned), C.byref(slot))
+    return int(owned.value), int(slot.value)
+
+
+def comm_unique_id() -> bytes:
+    buf = (C.c_uint8 * 128)()
+    rc = load_library().wr_comm_unique_id(buf)
+    if rc != WR_OK:
+        raise WrError(rc, "wr_comm_unique_id failed (is librccl.so.1 loadable?)")
+    return bytes(buf)
+
+
+def comm_create(uid: bytes, rank: int, world: int, device: int) -> int:
+    buf = (C.c_uint8 * 128)(*uid)
+    out = _P()
+    rc = load_library().wr_comm_create(buf, rank, world, device, C.byref(out))
+    if rc != WR_OK:
+        raise WrError(rc, "wr_comm_create failed")
+    return out.value
+
+
+def comm_destroy(comm: int) -> None:
+    load_library().wr_comm_destroy(comm)
 
 
 class Glb:
@@ -399,6 +441,14 @@ class Renderer:
 
     def scatter_bins(self, device_src: int, rank: int, world: int):
         self._check(self.lib.wr_scatter_bins(self.h, device_src, rank, world))
+
+    def gather_bins_via(self, transport: "Transport", root: int = 0):
+        self._check(self.lib.wr_gather_bins_via(self.h, C.byref(transport), root))
+
+    def gather_bins(self, comm: int, root: int = 0):
+        """wr_gather_bins: grouped RCCL sends of this rank's packed bins to `root`, queued behind
+        the frame on the context's stream."""
+        self._check(self.lib.wr_gather_bins(self.h, comm, root))
 
     def set_profiling(self, on: bool):
         self._check(self.lib.wr_set_profiling(self.h, int(on)))

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -26,6 +27,8 @@
 #include "wr_kernels.h"
 
 using namespace wr;
+
+struct ncclUniqueIdBytes { char internal[128]; };  // ncclUniqueId of rccl.h, passed by value
 
 static_assert(sizeof(WrModelVertex) == 56, "ModelVertex layout (model.rs:14-22)");
 static_assert(sizeof(WrInstanceRaw) == 100, "InstanceRaw layout (instance.rs:9-14)");
@@ -158,6 +161,8 @@ struct WrContext {
     FrameRes fr[kMaxFrames];
     int nfr = 1;   // frames in flight (WrConfig.frames_in_flight)
     int cur = 0;   // the set the most recent frame was submitted to
+    uint32_t* d_gather_send = nullptr;  // bin-sharded contexts: this rank's packed bins
+    uint32_t* d_gather_recv = nullptr;  // and, for the gathering rank, every rank's slot
     unsigned long long* d_counters = nullptr;
     uint32_t* d_err = nullptr;  // [0] error bits, [1] geometry bin items, [2] shadow bin items, [3] fog (unused)
 
@@ -289,6 +294,14 @@ int alloc_frame_targets(WrContext* ctx, Arena& ar, FrameRes* f, bool color) {
 int alloc_targets(WrContext* ctx) {
     free_targets(ctx);
     const size_t n = (size_t)ctx->W * ctx->H;
+    dfree(ctx->d_gather_send); dfree(ctx->d_gather_recv);
+    if (ctx->cfg.tile_world > 1) {
+        uint32_t owned = 0, slot = 0;
+        wr_gather_layout((uint32_t)ctx->W, (uint32_t)ctx->H, ctx->cfg.tile_world, ctx->cfg.tile_rank, &owned, &slot);
+        const size_t bin_bytes = (size_t)kBin * kBin * 4;
+        WR_HIP(hipMalloc(&ctx->d_gather_send, std::max<size_t>(slot, 1) * bin_bytes));
+        WR_HIP(hipMalloc(&ctx->d_gather_recv, std::max<size_t>((size_t)slot * ctx->cfg.tile_world, 1) * bin_bytes));
+    }
     for (int k = 0; k < ctx->nfr; ++k) {
         FrameRes* f = &ctx->fr[k];
         Arena ar;
@@ -296,6 +309,10 @@ int alloc_targets(WrContext* ctx) {
         if (rc != WR_OK) return rc;
         WR_HIP(hipMemset(f->blend.rp_slot, 0, n * 4));
         WR_HIP(hipMemset(f->d_color, 0, n * 4));
+        // bins a sharded context never renders keep defined contents: nothing drawn, far plane
+        WR_HIP(hipMemset(f->d_vis, 0xFF, n * 4));
+        hipLaunchKernelGGL(k_fill_f32, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, f->d_depth, n, 1.0f);
+        WR_HIP(hipStreamSynchronize(ctx->stream));
     }
     return WR_OK;
 }
@@ -448,6 +465,27 @@ void build_tables(float* t) {
     }
 }
 
+// fog.wgsl:131 samples the geometry depth with a Linear sampler at the fragment's own texel
+// centre; in f32, (px + 0.5) / width * W - 0.5 is not always exactly px, and then the
+// neighbouring texel enters the blend with a weight of a few 1e-6 (fog_max_depth restates
+// that arithmetic).  Returns whether, for any column or row, such a tap lies in another 64-pixel
+// bin than the fragment: a bin-sharded context then needs the depth of bins it does not own.
+// (1920x1080 and 3840x2160 have no such tap; 1000 or 720 pixels do.)
+bool depth_taps_cross_bins(int W, int H, float planes_w, float planes_h) {
+    auto axis = [](int n, float extent) {
+        for (int p = 0; p < n; ++p) {
+            const float u = ((float)p + 0.5f) / extent;
+            const float x = guard_coord(u * (float)n - 0.5f);
+            const float x0 = floorf(x);
+            const int i0 = clampi((int)x0, n), i1 = clampi((int)x0 + 1, n);
+            if (i0 / kBin != p / kBin) return true;
+            if (x - x0 != 0.0f && i1 / kBin != p / kBin) return true;
+        }
+        return false;
+    };
+    return axis(W, planes_w) || axis(H, planes_h);
+}
+
 FrameConsts make_consts(const WrContext* ctx, const WrCameraUniform* cam, const WrLightUniform* light,
                         const WrGlobalUniforms* glob) {
     FrameConsts fc;
@@ -470,6 +508,10 @@ FrameConsts make_consts(const WrContext* ctx, const WrCameraUniform* cam, const 
     fc.W = ctx->W; fc.H = ctx->H; fc.S = ctx->S;
     fc.tile_rank = (int)ctx->cfg.tile_rank;
     fc.tile_world = (int)(ctx->cfg.tile_world ? ctx->cfg.tile_world : 1);
+    fc.geom_tile_rank = fc.tile_rank; fc.geom_tile_world = fc.tile_world;
+    if (fc.tile_world > 1 && depth_taps_cross_bins(ctx->W, ctx->H, cam->planes[2], cam->planes[3])) {
+        fc.geom_tile_rank = 0; fc.geom_tile_world = 1;
+    }
     return fc;
 }
 
@@ -679,13 +721,13 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
         VertexIn vin{g.pos, g.uv, g.nrm, g.tan, g.bit, g.nv};
         hipLaunchKernelGGL(k_vs_geometry, grid1(g.nv), dim3(256), 0, ms, vin, f->vout, fc);
         hipLaunchKernelGGL(k_setup<false>, grid1(g.ntris, 1), dim3(256), 0, ms, f->vout.clip, g.nv, g.idx, g.ntris,
-                           f->geom.ws, ctx->W, ctx->H, fc.tile_rank, fc.tile_world);
+                           f->geom.ws, ctx->W, ctx->H, fc.geom_tile_rank, fc.geom_tile_world);
         hipLaunchKernelGGL(k_setup_clip<false>, dim3(256, 1, 1), dim3(64), 0, ms, f->vout.clip, g.nv, g.idx, f->geom.ws,
-                           ctx->W, ctx->H, fc.tile_rank, fc.tile_world);
+                           ctx->W, ctx->H, fc.geom_tile_rank, fc.geom_tile_world);
         if (lm.ntris)
             hipLaunchKernelGGL(k_setup_small, grid1(lm.ntris), dim3(256), 0, ms, lm.pos, lm.idx, lm.ntris, 0,
                                (passes & WR_PASS_LIGHT_DEBUG) ? 1 : 0, g.ntris, f->geom.ws, fc);
-        if ((rc = bin_and_raster(ctx, f, ms, f->geom, false, fc.tile_rank, fc.tile_world)) != WR_OK) return rc;
+        if ((rc = bin_and_raster(ctx, f, ms, f->geom, false, fc.geom_tile_rank, fc.geom_tile_world)) != WR_OK) return rc;
         if (prof) WR_HIP(hipEventRecord(ev[3], ms));
         WR_HIP(hipEventRecord(f->ev_geom_done, ms));
         return WR_OK;
@@ -947,7 +989,7 @@ void wr_destroy(WrContext* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_scene(ctx);
     free_targets(ctx);
-    dfree(ctx->d_tables); dfree(ctx->d_counters); dfree(ctx->d_err);
+    dfree(ctx->d_tables); dfree(ctx->d_counters); dfree(ctx->d_err); dfree(ctx->d_gather_send); dfree(ctx->d_gather_recv);
     for (int k = 0; k < WrContext::kEvFrames; ++k)
         for (int i = 0; i < WrContext::kEvPerFrame; ++i) if (ctx->ev[k][i]) (void)hipEventDestroy(ctx->ev[k][i]);
     for (FrameRes& f : ctx->fr) {
@@ -1201,6 +1243,127 @@ int wr_scatter_bins(WrContext* ctx, const void* device_src, uint32_t rank, uint3
                            (uint32_t*)const_cast<void*>(device_src), ctx->W, ctx->H, bx, nb, (int)rank, (int)world, 0);
     WR_HIP(hipGetLastError());
     return WR_OK;
+}
+
+// ----------------------------------------------------------------------------- bin gather
+void wr_gather_layout(uint32_t width, uint32_t height, uint32_t world, uint32_t rank, uint32_t* owned, uint32_t* slot_bins) {
+    const uint32_t bx = (width + kBin - 1) / kBin, by = (height + kBin - 1) / kBin, nb = bx * by;
+    if (world == 0) world = 1;
+    if (owned) *owned = rank < world && nb > rank ? (nb - rank + world - 1) / world : 0;
+    if (slot_bins) *slot_bins = (nb + world - 1) / world;
+}
+
+int wr_gather_bins_via(WrContext* ctx, const WrTransport* tp, uint32_t root) {
+    if (!ctx || !tp || !tp->send || !tp->recv) return fail(ctx, WR_ERR_INVALID_ARGUMENT, "null transport");
+    const uint32_t world = ctx->cfg.tile_world, rank = ctx->cfg.tile_rank;
+    if (world < 2) return fail(ctx, WR_ERR_INVALID_ARGUMENT, "the context is not bin-sharded (WrConfig.tile_world < 2)");
+    if (root >= world) return fail(ctx, WR_ERR_INVALID_ARGUMENT, "root rank out of range");
+    WR_HIP(hipSetDevice(ctx->cfg.device));
+    const int bx = (ctx->W + kBin - 1) / kBin, by = (ctx->H + kBin - 1) / kBin, nb = bx * by;
+    const size_t bin_bytes = (size_t)kBin * kBin * 4;
+    uint32_t owned = 0, slot = 0;
+    wr_gather_layout((uint32_t)ctx->W, (uint32_t)ctx->H, world, rank, &owned, &slot);
+    FrameRes* f = &ctx->fr[ctx->cur];
+    if (f->submitted) WR_HIP(hipStreamWaitEvent(ctx->stream, f->ev_done, 0));
+    auto check = [&](int rc, const char* what) { return rc == 0 ? WR_OK : fail(ctx, WR_ERR_DEVICE, std::string("bin gather: ") + what + " failed"); };
+    int rc;
+    if (rank != root) {
+        if (owned)
+            hipLaunchKernelGGL(k_pack_bins, dim3(owned), dim3(256), 0, ctx->stream, f->d_color, ctx->d_gather_send, ctx->W, ctx->H, bx, nb,
+                               (int)rank, (int)world, 1);
+        WR_HIP(hipGetLastError());
+        if (tp->group_start && (rc = check(tp->group_start(tp->user), "group start")) != WR_OK) return rc;
+        if (owned && (rc = check(tp->send(tp->user, ctx->d_gather_send, owned * bin_bytes, (int)root, ctx->stream), "send")) != WR_OK) return rc;
+        if (tp->group_end && (rc = check(tp->group_end(tp->user), "group end")) != WR_OK) return rc;
+        return WR_OK;
+    }
+    if (tp->group_start && (rc = check(tp->group_start(tp->user), "group start")) != WR_OK) return rc;
+    for (uint32_t r = 0; r < world; ++r) {
+        if (r == root) continue;
+        uint32_t owned_r = 0;
+        wr_gather_layout((uint32_t)ctx->W, (uint32_t)ctx->H, world, r, &owned_r, nullptr);
+        if (!owned_r) continue;
+        void* dst = reinterpret_cast<uint8_t*>(ctx->d_gather_recv) + (size_t)r * slot * bin_bytes;
+        if ((rc = check(tp->recv(tp->user, dst, owned_r * bin_bytes, (int)r, ctx->stream), "receive")) != WR_OK) return rc;
+    }
+    if (tp->group_end && (rc = check(tp->group_end(tp->user), "group end")) != WR_OK) return rc;
+    hipLaunchKernelGGL(k_scatter_gathered, dim3((uint32_t)nb), dim3(256), 0, ctx->stream, f->d_color, ctx->d_gather_recv, ctx->W, ctx->H, bx,
+                       nb, (int)world, (int)root, (int)slot);
+    WR_HIP(hipGetLastError());
+    return WR_OK;
+}
+
+// RCCL, loaded on first use: a host that never gathers does not need the library present.
+extern "C++" {
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, ncclUniqueIdBytes, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    bool ok = false;
+};
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) return;
+        auto sym = [&](const char* n) { return dlsym(r.lib, n); };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+        r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+        r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv;
+    });
+    return r;
+}
+constexpr int kNcclUint8 = 1;  // ncclUint8 of rccl.h
+int rccl_group_start(void*) { return rccl().GroupStart(); }
+int rccl_group_end(void*) { return rccl().GroupEnd(); }
+int rccl_send(void* comm, const void* buf, size_t bytes, int peer, void* stream) {
+    return rccl().Send(buf, bytes, kNcclUint8, peer, comm, (hipStream_t)stream);
+}
+int rccl_recv(void* comm, void* buf, size_t bytes, int peer, void* stream) {
+    return rccl().Recv(buf, bytes, kNcclUint8, peer, comm, (hipStream_t)stream);
+}
+}  // namespace
+}  // extern "C++"
+
+int wr_gather_bins(WrContext* ctx, void* nccl_comm, uint32_t root) {
+    if (!ctx || !nccl_comm) return fail(ctx, WR_ERR_INVALID_ARGUMENT, "null communicator");
+    if (!rccl().ok) return fail(ctx, WR_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded");
+    WrTransport tp{nccl_comm, rccl_group_start, rccl_send, rccl_recv, rccl_group_end};
+    return wr_gather_bins_via(ctx, &tp, root);
+}
+int wr_comm_unique_id(uint8_t id[128]) {
+    if (!id) return WR_ERR_INVALID_ARGUMENT;
+    if (!rccl().ok) return WR_ERR_UNSUPPORTED;
+    return rccl().GetUniqueId(id) == 0 ? WR_OK : WR_ERR_DEVICE;
+}
+int wr_comm_create(const uint8_t id[128], uint32_t rank, uint32_t world, int32_t device, void** out_comm) {
+    if (!id || !out_comm || rank >= world) return WR_ERR_INVALID_ARGUMENT;
+    *out_comm = nullptr;
+    if (!rccl().ok) return WR_ERR_UNSUPPORTED;
+    if (hipSetDevice(device) != hipSuccess) return WR_ERR_DEVICE;
+    ncclUniqueIdBytes uid;
+    memcpy(uid.internal, id, sizeof(uid.internal));
+    return rccl().CommInitRank(out_comm, (int)world, uid, (int)rank) == 0 ? WR_OK : WR_ERR_DEVICE;
+}
+int wr_comm_destroy(void* comm) {
+    if (!comm) return WR_OK;
+    if (!rccl().ok) return WR_ERR_UNSUPPORTED;
+    return rccl().CommDestroy(comm) == 0 ? WR_OK : WR_ERR_DEVICE;
 }
 
 int wr_set_profiling(WrContext* ctx, int enabled) {

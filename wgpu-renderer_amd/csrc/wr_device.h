@@ -167,6 +167,9 @@ struct FrameConsts {
     uint32_t light_tame;     // every entry of light_m is finite and below 1e15 in magnitude
     int W, H, S;
     int tile_rank, tile_world;
+    // Which bins the geometry pass (visibility + depth) covers: the context's own, or all of
+    // them (0, 1) when the fog pass's depth lookups reach into neighbouring bins.
+    int geom_tile_rank, geom_tile_world;
 };
 
 // ---------------------------------------------------------------------------------------

@@ -394,7 +394,7 @@ __global__ void k_setup_small(const float4* pos, const uint32_t* idx, uint32_t n
             else wp = mat4_mul(fc.model_fog, V4{p.x, p.y, p.z, 1.0f});
             c[k] = mat4_mul(fc.pv, wp);
         }
-    SetupTarget tg = setup_target(ws, 0, fc.W, fc.H, fc.tile_rank, fc.tile_world);
+    SetupTarget tg = setup_target(ws, 0, fc.W, fc.H, fc.geom_tile_rank, fc.geom_tile_world);
     tg.count = mode == 0;
     emit_triangle<false, false>(have, c, slot_base + t, slot_base + t, ws, tg);
 }
@@ -1485,6 +1485,24 @@ __global__ __launch_bounds__(256) void k_pack_bins(const uint32_t* color, uint32
         bool in = px < W && py < H;
         if (to_packed) packed[po] = in ? color[(size_t)py * W + px] : 0u;
         else if (in) const_cast<uint32_t*>(color)[(size_t)py * W + px] = packed[po];
+    }
+}
+
+// The gathering rank's side of a bin gather: bin b of the frame belongs to rank b % world and is
+// that rank's (b / world)-th bin; rank r's packed bins start at r * slot_bins in `gathered`.
+// The root's own bins are in place already.
+__global__ __launch_bounds__(256) void k_scatter_gathered(uint32_t* color, const uint32_t* gathered, int W, int H, int bins_x,
+                                                          int nbins, int world, int root, int slot_bins) {
+    latency_bound_kernel();
+    const int b = blockIdx.x;
+    if (b >= nbins) return;
+    const int r = b % world, j = b / world;
+    if (r == root) return;
+    const uint32_t* src = gathered + ((size_t)r * slot_bins + j) * (kBin * kBin);
+    const int ox = (b % bins_x) * kBin, oy = (b / bins_x) * kBin;
+    for (int i = threadIdx.x; i < kBin * kBin; i += 256) {
+        const int px = ox + (i & (kBin - 1)), py = oy + i / kBin;
+        if (px < W && py < H) color[(size_t)py * W + px] = src[i];
     }
 }
 
