@@ -490,6 +490,51 @@ def test_full_size_properties(full_scene):
     gathered.close()
 
 
+def test_512_pose_flythrough_batch_at_full_size(full_scene):
+    """BASELINE configs[4] at its size: the 512-pose flythrough at 1920x1080 with shadows and fog
+    through wr_render_batch into 4.25 GB of device frames, with the light fixed (shadow maps
+    rendered once, then once per pose) and with t = 2 + k/60 (light, fog drift and shadow maps
+    change every frame, frames rotating through four sets of buffers).  Sampled frames equal
+    single wr_render_frame calls bit for bit, one of them is checked against the oracle."""
+    import torch
+    w, h, s, n = 1920, 1080, 2048, 512
+    poses = [scene.flythrough_pose(k, n) for k in range(n)]
+    cams = [default_inputs(w, h, pose=p)[0] for p in poses]
+    light, glob = abi.light_at_time(2.0), abi.global_uniforms(2.0, 1)
+    sample = [0, 1, 63, 64, 200, 255, 300, 511]
+    one = abi.Renderer(w, h, s)
+    one.upload_scene(full_scene)
+    ref = {}
+    for k in sample:
+        one.render_frame(cams[k], light, glob, abi.PASS_ALL)
+        ref[k] = one.read_color()
+    o = render_oracle(full_scene, cams[300], light, glob, abi.PASS_ALL, w, h, s, threads=16)
+    assert np.array_equal(ref[300], o["color"])
+    assert len({ref[k].tobytes() for k in sample}) == len(sample)  # the poses really differ
+    r = abi.Renderer(w, h, s, frames_in_flight=4)
+    r.upload_scene(full_scene)
+    frames = torch.empty((n, h, w, 4), dtype=torch.uint8, device="cuda")
+    for every in (False, True):
+        frames.zero_()
+        r.render_batch(cams, light, glob, abi.PASS_ALL, shadows_every_frame=every, device_frames=frames.data_ptr())
+        r.sync()
+        torch.cuda.synchronize()
+        for k in sample:
+            assert np.array_equal(frames[k].cpu().numpy(), ref[k]), (every, k)
+        assert int((frames.view(n, -1)[:, 3::4] != 0).all(dim=1).sum()) == n  # every frame was delivered (alpha is never 0)
+    del frames
+    # animated: one wr_render_frame per pose, four frames in flight
+    for k in range(n):
+        t = 2.0 + k / 60.0
+        r.render_frame(cams[k], abi.light_at_time(t), abi.global_uniforms(t, 1), abi.PASS_ALL)
+        if k in sample:
+            got = r.read_color()
+            one.render_frame(cams[k], abi.light_at_time(t), abi.global_uniforms(t, 1), abi.PASS_ALL)
+            assert np.array_equal(got, one.read_color()), k
+    r.close()
+    one.close()
+
+
 def test_4k_bin_sharding_over_eight_contexts(full_scene):
     """BASELINE configs[3]: 3840x2160 with the 64x64 bins interleaved over eight ranks; the
     gathered frame equals the frame one context renders alone."""
