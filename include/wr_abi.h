@@ -104,13 +104,15 @@ enum {
     WR_PASS_ALL = 7u
 };
 
-enum { WR_FORMAT_RGBA8_UNORM_SRGB = 0 };
+/* Colour target formats (state.rs:106 takes caps.formats[0]: Bgra8UnormSrgb on most Vulkan
+ * surfaces, Rgba8UnormSrgb on some).  Both hold the same values, bytes in the order named. */
+enum { WR_FORMAT_RGBA8_UNORM_SRGB = 0, WR_FORMAT_BGRA8_UNORM_SRGB = 1 };
 
 typedef struct WrConfig {
     uint32_t width;           /* state.rs:104-108 surface size */
     uint32_t height;
     uint32_t shadow_map_size; /* state.rs:18 SHADOW_MAP_SIZE (2048); 0 selects 2048 */
-    uint32_t color_format;    /* state.rs:106 caps.formats[0]; only RGBA8 sRGB here */
+    uint32_t color_format;    /* state.rs:106 caps.formats[0]: WR_FORMAT_RGBA8_UNORM_SRGB or WR_FORMAT_BGRA8_UNORM_SRGB */
     int32_t device;           /* HIP device ordinal */
     /* Screen-bin sharding across contexts: this context produces only the 64x64-pixel
      * bins b (row-major bin index) with b % tile_world == tile_rank.  tile_world 0 or 1
@@ -245,8 +247,8 @@ int wr_sync(WrContext* ctx);
 
 /* ------------------------------------------------------------------ results */
 
-/* Synchronous copies to host memory.  Colour is RGBA8 (sRGB-encoded), row-major, top row
- * first: the surface texture of state.rs:678-681.  Depth is the geometry depth texture
+/* Synchronous copies to host memory.  Colour is RGBA8 or BGRA8 (WrConfig.color_format;
+ * sRGB-encoded), row-major, top row first: the surface texture of state.rs:678-681.  Depth is the geometry depth texture
  * (state.rs:562-573).  Visibility is, per pixel, (triangle id << 3 | clip-fan index) of
  * the fragment that owns the depth value, 0xFFFFFFFF where nothing was drawn; ids of the
  * light marker continue after the geometry model's.  Shadow is the 6-layer depth array

@@ -35,7 +35,7 @@ def write_png(path, rgba):
                 chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="frames")
     ap.add_argument("--poses", type=int, default=8)
@@ -45,11 +45,12 @@ def main():
     ap.add_argument("--detail", type=float, default=1.0)
     ap.add_argument("--tex-size", type=int, default=1024)
     ap.add_argument("--time", type=float, default=2.0)
+    ap.add_argument("--shadow-map-size", type=int, default=2048)
     ap.add_argument("--sponza", default="")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     os.makedirs(args.out, exist_ok=True)
     W, H = args.width, args.height
-    r = abi.Renderer(W, H, 2048)
+    r = abi.Renderer(W, H, args.shadow_map_size)
     if args.sponza:
         from wgpu_renderer_amd import gltf_loader
         model, textures = gltf_loader.load_glb(args.sponza)

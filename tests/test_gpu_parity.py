@@ -387,6 +387,23 @@ def test_degenerate_and_extreme_triangles():
     assert (o["vis"] != 0xFFFFFFFF).mean() > 0.9  # the huge triangle was clipped, not dropped
 
 
+def test_bgra_target_is_the_rgba_frame_with_red_and_blue_exchanged(tiny_scene):
+    # state.rs:106 takes the surface's first format, Bgra8UnormSrgb on most Vulkan surfaces
+    w, h, s = 333, 207, 128
+    cam, light, glob = default_inputs(w, h)
+    rgba = render_gpu(tiny_scene, cam, light, glob, abi.PASS_ALL, w, h, s)["color"]
+    for in_flight in (1, 2):
+        r = abi.Renderer(w, h, s, color_format=abi.FORMAT_BGRA8_UNORM_SRGB, frames_in_flight=in_flight)
+        r.upload_scene(tiny_scene)
+        for _ in range(3):  # the same buffers frame after frame: the exchange happens once per frame
+            r.render_frame(cam, light, glob, abi.PASS_ALL)
+        bgra = r.read_color()
+        r.close()
+        assert np.array_equal(bgra[..., [2, 1, 0, 3]], rgba) and (rgba[..., 0] != rgba[..., 2]).any()
+    with pytest.raises(abi.WrError):
+        abi.Renderer(w, h, s, color_format=7)
+
+
 def test_resize_and_scene_reuse(tiny_scene):
     cam, light, glob = default_inputs(200, 120)
     r = abi.Renderer(200, 120, 128)

@@ -21,6 +21,7 @@ WR_ERR_INVALID_ARGUMENT = -1
 WR_ERR_OUT_OF_MEMORY = -2
 WR_ERR_DEVICE = -3
 WR_ERR_UNSUPPORTED = -4
+FORMAT_RGBA8_UNORM_SRGB, FORMAT_BGRA8_UNORM_SRGB = 0, 1
 WR_ERR_CAPACITY = -5
 WR_ERR_NO_SCENE = -6
 
@@ -317,9 +318,10 @@ class Renderer:
     keeps its wgpu Device/Queue/pipelines (state.rs:30-66)."""
 
     def __init__(self, width: int, height: int, shadow_map_size: int = 2048, device: int = 0,
-                 tile_rank: int = 0, tile_world: int = 1, stream: Optional[int] = None, frames_in_flight: int = 1):
+                 tile_rank: int = 0, tile_world: int = 1, stream: Optional[int] = None, frames_in_flight: int = 1,
+                 color_format: int = 0):
         self.lib = load_library()
-        cfg = Config(width, height, shadow_map_size, 0, device, tile_rank, tile_world, stream, frames_in_flight, 0)
+        cfg = Config(width, height, shadow_map_size, color_format, device, tile_rank, tile_world, stream, frames_in_flight, 0)
         h = _P()
         rc = self.lib.wr_create(C.byref(cfg), C.byref(h))
         if rc != WR_OK:

@@ -859,6 +859,8 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
         if (ctx->counting) hipLaunchKernelGGL(k_fog_multi<true>, dim3(1024), dim3(64), 0, ms, fa);
         else hipLaunchKernelGGL(k_fog_multi<false>, dim3(1024), dim3(64), 0, ms, fa);
     }
+    if (ctx->cfg.color_format == WR_FORMAT_BGRA8_UNORM_SRGB)
+        hipLaunchKernelGGL(k_swap_red_blue, dim3(1024), dim3(256), 0, ms, f->d_color, npx);
     if (prof) {
         WR_HIP(hipEventRecord(ev[7], ms));
         ctx->ev_next = (ctx->ev_next + 1) % WrContext::kEvFrames;
@@ -907,7 +909,7 @@ int wr_create(const WrConfig* config, WrContext** out_ctx) {
     if (!config || !out_ctx) return WR_ERR_INVALID_ARGUMENT;
     *out_ctx = nullptr;
     if (config->width == 0 || config->height == 0 || config->width > 7168 || config->height > 7168) return WR_ERR_INVALID_ARGUMENT;
-    if (config->color_format != WR_FORMAT_RGBA8_UNORM_SRGB) return WR_ERR_UNSUPPORTED;
+    if (config->color_format != WR_FORMAT_RGBA8_UNORM_SRGB && config->color_format != WR_FORMAT_BGRA8_UNORM_SRGB) return WR_ERR_UNSUPPORTED;
     uint32_t S = config->shadow_map_size ? config->shadow_map_size : 2048u;
     if (S > 7168) return WR_ERR_INVALID_ARGUMENT;
     if (config->tile_world > 1 && config->tile_rank >= config->tile_world) return WR_ERR_INVALID_ARGUMENT;

@@ -1506,6 +1506,17 @@ __global__ __launch_bounds__(256) void k_scatter_gathered(uint32_t* color, const
     }
 }
 
+// Bgra8UnormSrgb target: the frame is composed as RGBA (every blend works per channel, so the
+// order of the bytes does not enter any result) and the red and blue bytes change places once,
+// at the end of the frame.
+__global__ __launch_bounds__(256) void k_swap_red_blue(uint32_t* color, size_t n) {
+    latency_bound_kernel();
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) {
+        const uint32_t c = color[i];
+        color[i] = (c & 0xFF00FF00u) | ((c & 0xFFu) << 16) | ((c >> 16) & 0xFFu);
+    }
+}
+
 // Zeroes the per-frame counter blocks of one stream in a single launch.
 struct ClearList { uint32_t* ptr[4]; uint32_t words[4]; };
 __global__ __launch_bounds__(256) void k_clear_words(ClearList c) {
