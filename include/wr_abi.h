@@ -12,9 +12,12 @@
  *   - return 0 (WR_OK) on success, a negative WrStatus on failure; wr_last_error()
  *     gives a text for the last failure on that context.  Nothing throws or aborts.
  *   - the caller owns every input pointer; the library copies during the call.
- *   - one caller thread per context, calls are executed in order on one HIP stream
- *     (the reference drives wgpu from the single winit event-loop thread,
- *     src/core/window.rs:55-69, and wgpu queues execute in submission order).
+ *   - one caller thread per context (the reference drives wgpu from the single winit
+ *     event-loop thread, src/core/window.rs:55-69).  Calls take effect in call order, as
+ *     wgpu queues execute in submission order.  A frame's kernels run on streams the library
+ *     owns (three per frame in flight: geometry + shading, shadow passes, fog), forked from
+ *     and -- with one frame in flight -- joined back into WrConfig.stream; see
+ *     WrConfig.frames_in_flight for what the caller's stream may assume.
  *   - all matrices are column-major [[f32;4];4] exactly as cgmath/bytemuck lay them out.
  */
 #ifndef WR_ABI_H
@@ -136,8 +139,11 @@ typedef struct WrConfig {
 typedef struct WrContext WrContext;
 
 /* Per-stage device times and per-frame counters.  Times are HIP-event milliseconds, averaged
- * over the (at most 128 most recent) frames rendered since wr_set_profiling(ctx, 1); counters
- * are those of the last frame.  The shadow pass runs on a library-owned side stream next to
+ * over the (at most 128 most recent) frames rendered since wr_set_profiling(ctx, 1).  The
+ * "counting mode" counters are those of the last wr_render_* call (summed over the poses of a
+ * batch); a counted call waits on the device for the frames still in flight, so its counters
+ * are its own.  The two *_bin_items counts are written by every frame: with several frames in
+ * flight they are those of one of the most recent frames.  The shadow pass runs on a library-owned side stream next to
  * the geometry pass, so ms_shadow and ms_geometry overlap, ms_shade includes any wait for the
  * shadow maps, and ms_total is the frame from first to last kernel, not the sum.  No
  * counterpart in the reference (timestamp_writes: None on every pass,
@@ -208,8 +214,11 @@ int wr_clear_scene(WrContext* ctx);
 /* ------------------------------------------------------------------ per frame */
 
 /* Replaces the three queue.write_buffer calls of State::update (state.rs:603-607,619-623,
- * 635-639) plus all of State::render (state.rs:630-809).  Asynchronous: work is enqueued
- * on the context's stream.  `passes` is a mask of WR_PASS_*. */
+ * 635-639) plus all of State::render (state.rs:630-809).  Asynchronous: the frame is queued
+ * behind what WrConfig.stream holds at the time of the call and runs on the library's own
+ * streams.  `passes` is a mask of WR_PASS_*.  A frame without WR_PASS_SHADOWS samples cleared
+ * shadow maps (depth 1.0: nothing is in shadow) if globals->use_shadowmaps is set; the
+ * reference's configuration without shadow passes sets it to 0 (state.rs:627). */
 int wr_render_frame(WrContext* ctx, const WrCameraUniform* camera, const WrLightUniform* light,
                     const WrGlobalUniforms* globals, uint32_t passes);
 
@@ -218,7 +227,7 @@ int wr_render_frame(WrContext* ctx, const WrCameraUniform* camera, const WrLight
  * `shadows_every_frame` != 0 (then every pose repeats them, as consecutive State::render
  * calls would).  If `device_frames` is not NULL it must be device memory for
  * count*width*height*4 bytes and receives every finished frame; otherwise only the last
- * frame stays readable. */
+ * frame stays readable.  count == 0 renders nothing and leaves the readable frame as it is. */
 int wr_render_batch(WrContext* ctx, const WrCameraUniform* cameras, uint32_t count,
                     const WrLightUniform* light, const WrGlobalUniforms* globals,
                     uint32_t passes, int shadows_every_frame, void* device_frames);
@@ -314,7 +323,8 @@ int wr_comm_destroy(void* comm);
 
 int wr_set_profiling(WrContext* ctx, int enabled);
 /* enabled != 0 makes the next frames also count fragments / march steps with atomics
- * (slower; never enable it inside a timed region). */
+ * (slower, and a counted call does not overlap the frames before it; never enable it inside
+ * a timed region). */
 int wr_set_counting(WrContext* ctx, int enabled);
 int wr_get_stats(WrContext* ctx, WrFrameStats* out);
 

@@ -302,6 +302,45 @@ def test_frames_in_flight_match_one(small_scene, in_flight):
     two.close()
 
 
+@pytest.mark.parametrize("in_flight", [1, 3])
+def test_state_shared_between_frames_in_flight(small_scene, in_flight):
+    """What frames share across the sets of frame buffers: a frame without shadow passes sees
+    cleared maps whichever set it lands on, the counters of a counted frame are its own although
+    other frames are still running, and an empty batch changes nothing."""
+    w, h, s = 400, 225, 256
+    cam, light, glob = default_inputs(w, h)
+    no_shadow_pass = abi.PASS_FOG | abi.PASS_LIGHT_DEBUG
+    fresh = render_gpu(small_scene, cam, light, glob, no_shadow_pass, w, h, s)
+    full = render_gpu(small_scene, cam, light, glob, abi.PASS_ALL, w, h, s, counting=True)
+    assert not np.array_equal(fresh["color"], full["color"])
+    r = abi.Renderer(w, h, s, frames_in_flight=in_flight)
+    r.upload_scene(small_scene)
+    for _ in range(in_flight):  # every set has drawn shadow maps
+        r.render_frame(cam, light, glob, abi.PASS_ALL)
+    for _ in range(in_flight + 1):  # a frame without the passes, on every set
+        r.render_frame(cam, light, glob, no_shadow_pass)
+        assert np.array_equal(r.read_color(), fresh["color"])
+    assert (r.read_shadow_map() == 1.0).all()
+    r.render_frame(cam, light, glob, abi.PASS_ALL)
+    assert np.array_equal(r.read_color(), full["color"])
+    # counted frame behind uncounted frames still in flight
+    other = default_inputs(w, h, pose=scene.flythrough_pose(5, 64))[0]
+    for _ in range(4):
+        r.render_frame(other, light, glob, abi.PASS_ALL)
+    r.set_counting(True)
+    r.render_frame(cam, light, glob, abi.PASS_ALL)
+    st = r.stats()
+    r.set_counting(False)
+    assert dict(fog_fragments=int(st.fog_fragments), fog_noise_evals=int(st.fog_noise_evals), replay_pixels=int(st.replay_pixels),
+                replay_slow_pixels=int(st.replay_slow_pixels)) == full["counters"]
+    assert full["counters"]["fog_noise_evals"] > 0
+    # an empty batch
+    before = r.read_color()
+    r.render_batch([], light, glob, abi.PASS_ALL)
+    assert np.array_equal(r.read_color(), before) and np.array_equal(before, full["color"])
+    r.close()
+
+
 def test_scene_uploaded_through_the_native_glb_importer(tmp_path):
     """wr_upload_glb (C++ importer) and the Python loader + wr_upload_* give the same frame."""
     from test_abi_and_host import _synthetic_glb

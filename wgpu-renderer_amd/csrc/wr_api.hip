@@ -117,6 +117,9 @@ struct FrameRes {
     hipStream_t ms = nullptr, side = nullptr, fs = nullptr;
     hipEvent_t ev_fork = nullptr, ev_start = nullptr, ev_join = nullptr, ev_shadow_done = nullptr, ev_geom_done = nullptr, ev_done = nullptr;
     bool submitted = false;  // ev_done has been recorded
+    // d_shadow holds the cleared depth (1.0 everywhere), the value a frame without shadow passes
+    // samples: as at allocation, until a shadow pass draws into it
+    bool shadow_is_clear = true;
 
     VertexOut vout{};
     float4* d_shadow_clip = nullptr;
@@ -735,8 +738,17 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
     auto submit_shadows = [&]() -> int {
         // side stream: shadow maps
         if (prof) WR_HIP(hipEventRecord(ev[1], ss));
-        if (do_shadow && (passes & WR_PASS_SHADOWS))
+        if (do_shadow && (passes & WR_PASS_SHADOWS)) {
             if ((rc = shadow_stage(ctx, f, ss, fc)) != WR_OK) return rc;
+            f->shadow_is_clear = false;
+        } else if (do_shadow && !f->shadow_is_clear) {
+            // No shadow passes in this frame: it sees cleared maps, whatever frame used this set
+            // of buffers before (the reference clears each face to 1.0 before drawing into it,
+            // state.rs:655-657; a frame that draws nothing leaves that).
+            const size_t ns = (size_t)6 * ctx->S * ctx->S;
+            hipLaunchKernelGGL(k_fill_f32, dim3((uint32_t)((ns + 255) / 256)), dim3(256), 0, ss, f->d_shadow, ns, 1.0f);
+            f->shadow_is_clear = true;
+        }
         if (prof) WR_HIP(hipEventRecord(ev[2], ss));
         WR_HIP(hipEventRecord(f->ev_shadow_done, ss));
         return WR_OK;
@@ -876,6 +888,16 @@ int finish_frame(WrContext* ctx, FrameRes* f) {
     WR_HIP(hipEventRecord(f->ev_done, f->ms));
     f->submitted = true;
     if (ctx->nfr == 1) WR_HIP(hipStreamWaitEvent(ctx->stream, f->ev_done, 0));
+    return WR_OK;
+}
+
+// Counting mode.  The counters are one block for all sets of frame buffers, so a counted call
+// starts after every frame still in flight: its counters are its own.
+int begin_counted(WrContext* ctx) {
+    if (!ctx->counting) return WR_OK;
+    for (int k = 0; k < ctx->nfr; ++k)
+        if (ctx->fr[k].submitted) WR_HIP(hipStreamWaitEvent(ctx->stream, ctx->fr[k].ev_done, 0));
+    WR_HIP(hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
     return WR_OK;
 }
 
@@ -1090,7 +1112,7 @@ int wr_render_frame(WrContext* ctx, const WrCameraUniform* camera, const WrLight
     if (!ctx || !camera || !light || !globals) return fail(ctx, WR_ERR_INVALID_ARGUMENT, "null uniform");
     int rc = check_ready(ctx, passes);
     if (rc != WR_OK) return rc;
-    if (ctx->counting) WR_HIP(hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    if ((rc = begin_counted(ctx)) != WR_OK) return rc;
     FrameConsts fc = make_consts(ctx, camera, light, globals);
     FrameRes* f = next_frame(ctx);
     if ((rc = frame_stages(ctx, f, fc, passes, true)) != WR_OK) return rc;
@@ -1145,7 +1167,7 @@ int wr_render_frame_static(WrContext* ctx, const WrCameraUniform* camera, const 
         const size_t ns = (size_t)6 * ctx->S * ctx->S;
         hipLaunchKernelGGL(k_fill_f32, dim3((uint32_t)((ns + 255) / 256)), dim3(256), 0, ctx->stream, sf.d_shadow, ns, 1.0f);
     }
-    if (ctx->counting) WR_HIP(hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    if ((rc = begin_counted(ctx)) != WR_OK) return rc;
     FrameConsts fc = make_consts(ctx, camera, light, globals);
     if ((rc = frame_stages(ctx, &sf, fc, passes, true)) != WR_OK) return rc;
     WR_HIP(hipEventRecord(sf.ev_done, sf.ms));
@@ -1156,10 +1178,11 @@ int wr_render_frame_static(WrContext* ctx, const WrCameraUniform* camera, const 
 
 int wr_render_batch(WrContext* ctx, const WrCameraUniform* cameras, uint32_t count, const WrLightUniform* light,
                     const WrGlobalUniforms* globals, uint32_t passes, int shadows_every_frame, void* device_frames) {
-    if (!ctx || !cameras || !light || !globals) return fail(ctx, WR_ERR_INVALID_ARGUMENT, "null uniform");
+    if (!ctx || (!cameras && count) || !light || !globals) return fail(ctx, WR_ERR_INVALID_ARGUMENT, "null uniform");
     int rc = check_ready(ctx, passes);
     if (rc != WR_OK) return rc;
-    if (ctx->counting) WR_HIP(hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    if (count == 0) return WR_OK;  // nothing to render: the most recent frame stays the one read back
+    if ((rc = begin_counted(ctx)) != WR_OK) return rc;
     size_t frame_bytes = (size_t)ctx->W * ctx->H * 4;
     FrameRes* f = next_frame(ctx);
     for (uint32_t i = 0; i < count; ++i) {

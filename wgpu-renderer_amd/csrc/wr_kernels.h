@@ -467,8 +467,8 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(RasterWS ws) {
 // over the colour target's bins that hold pixels flagged for ordered blending; every
 // fragment covering such a pixel is appended to the pixel's list.
 //
-// The bin's triangle list is consumed 1024 records at a time, one record per thread, all
-// loads in flight together.  A triangle of at most 64x64 pixels with at most
+// The bin's triangle list is consumed one workgroup's worth of records (THREADS, 256 in this
+// build) at a time, one record per thread, all loads in flight together.  A triangle of at most 64x64 pixels with at most
 // WR_RASTER_LANE_AREA pixels of its box inside the bin is rasterised by the thread that
 // fetched it (64 triangles per wavefront in flight, 32-bit stepped edge functions); larger
 // ones are queued in LDS and then taken one per wavefront, 64 lanes testing one 8x8 pixel
@@ -534,9 +534,11 @@ __device__ inline void raster_emit(const Rec& r, float z, int li, unsigned long 
 #ifndef WR_RASTER_LANE_AREA
 #define WR_RASTER_LANE_AREA 128
 #endif
-// THREADS: 256 for the shadow faces (6144 mostly short lists: more bins in flight per CU),
-// 1024 for the colour target (few bins, some with thousands of triangles: 16 wavefronts
-// sharing the tile shorten the longest lists).
+// THREADS is chosen by the host per target; both targets use 256.  The shadow faces have 6144
+// mostly short lists, where small workgroups keep more bins in flight per CU.  The colour
+// target has few bins, some with thousands of triangles, where 1024 threads sharing the tile
+// shorten the longest lists; measured, that gained less than the smaller groups' better
+// overlap with the kernels of the neighbouring streams.
 #ifdef WR_DEV
 __device__ unsigned long long g_dbg_cycles[3 * 40000];
 #endif
