@@ -44,8 +44,14 @@ constexpr int kColorRasterThreads = WR_COLOR_RASTER_THREADS;
 #define WR_SHADOW_RASTER_THREADS 256
 #endif
 constexpr int kShadowRasterThreads = WR_SHADOW_RASTER_THREADS;
-constexpr size_t kNoiseLevelEntries = 4u << 20;  // largest hash table of one noise level
-constexpr size_t kNoisePoolEntries = 8u << 20;    // all levels together (32 MB per frame in flight)
+#ifndef WR_NOISE_LEVEL_ENTRIES
+#define WR_NOISE_LEVEL_ENTRIES (4u << 20)
+#endif
+#ifndef WR_NOISE_POOL_ENTRIES
+#define WR_NOISE_POOL_ENTRIES (8u << 20)
+#endif
+constexpr size_t kNoiseLevelEntries = WR_NOISE_LEVEL_ENTRIES;  // largest hash table of one noise level
+constexpr size_t kNoisePoolEntries = WR_NOISE_POOL_ENTRIES;    // all levels together (4 bytes each, per frame in flight)
 static_assert(sizeof(FrameConsts) < 3072, "FrameConsts must fit the kernel argument segment");
 
 // Work buffers of wr_render_frame_static, the entry point for callers that cannot allocate.
@@ -662,6 +668,9 @@ NoiseTables plan_noise_tables(const WrContext* ctx, const FrameRes* f, const Fra
                 n[r] = (long)std::floor(b) + 2 - l[r] + 1;
             }
             double entries = (double)n[0] * n[1] * n[2];
+#ifdef WR_DEV
+            if (getenv("WR_DEBUG_TABLES")) fprintf(stderr, "noise level %d/%d: %ld x %ld x %ld = %.0f entries\n", k, o, n[0], n[1], n[2], entries);
+#endif
             if (entries > (double)std::min(kNoiseLevelEntries, f->noise_pool_entries) || used + (size_t)entries > f->noise_pool_entries) continue;
             NoiseTable& t = nt.level[k * 8 + o];
             t.data = f->d_noise_pool + used;
@@ -745,7 +754,7 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
             // No shadow passes in this frame: it sees cleared maps, whatever frame used this set
             // of buffers before (the reference clears each face to 1.0 before drawing into it,
             // state.rs:655-657; a frame that draws nothing leaves that).
-            const size_t ns = (size_t)6 * ctx->S * ctx->S;
+            const size_t ns = shadow_buffer_floats(ctx->S);
             hipLaunchKernelGGL(k_fill_f32, dim3((uint32_t)((ns + 255) / 256)), dim3(256), 0, ss, f->d_shadow, ns, 1.0f);
             f->shadow_is_clear = true;
         }
@@ -770,7 +779,7 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
                     const NoiseTable& t = fa.tables_noise.level[l];
                     plan.xchunks[l] = plan.ychunks[l] = 1u;
                     plan.wg_begin[l + 1] = plan.wg_begin[l];
-                    if (t.data) plan_table_level(plan, l, t.nx, t.ny, t.nz);
+                    if (t.data) plan_table_level(plan, l, t);
                 }
                 hipLaunchKernelGGL(k_fog_tables, dim3(plan.wg_begin[16]), dim3(256), 0, fs, fa.tables_noise, plan);
             }
@@ -985,7 +994,7 @@ int wr_create(const WrConfig* config, WrContext** out_ctx) {
         WR_HIP(hipMemset(ctx->d_counters, 0, 8 * sizeof(unsigned long long)));
         WR_HIP(hipMalloc(&ctx->d_err, 4 * sizeof(uint32_t)));
         WR_HIP(hipMemset(ctx->d_err, 0, 4 * sizeof(uint32_t)));
-        size_t ns = (size_t)6 * S * S;
+        size_t ns = shadow_buffer_floats((int)S);  // faces, then the depth range of their 8x8 tiles
         for (int k = 0; k < ctx->nfr; ++k) {
             FrameRes* f = &ctx->fr[k];
             WR_HIP(hipMalloc(&f->d_noise_pool, kNoisePoolEntries * sizeof(float)));
@@ -1122,7 +1131,7 @@ int wr_render_frame(WrContext* ctx, const WrCameraUniform* camera, const WrLight
 // The work buffers of one frame, carved from `ar` (no allocation): shadow maps, noise tables,
 // target-sized and scene-sized buffers.  The colour target is the caller's.
 static int carve_static_frame(WrContext* ctx, Arena& ar, FrameRes* f) {
-    WR_HIP(arena_take(ar, f->d_shadow, (size_t)6 * ctx->S * ctx->S * 4));
+    WR_HIP(arena_take(ar, f->d_shadow, shadow_buffer_floats(ctx->S) * 4));
     WR_HIP(arena_take(ar, f->d_noise_pool, kStaticNoisePoolEntries * sizeof(float)));
     f->noise_pool_entries = kStaticNoisePoolEntries;
     int rc = alloc_frame_targets(ctx, ar, f, false);
@@ -1164,7 +1173,7 @@ int wr_render_frame_static(WrContext* ctx, const WrCameraUniform* camera, const 
     const size_t npx = (size_t)ctx->W * ctx->H;
     WR_HIP(hipMemsetAsync(sf.blend.rp_slot, 0, npx * 4, ctx->stream));
     if (!(passes & WR_PASS_SHADOWS)) {
-        const size_t ns = (size_t)6 * ctx->S * ctx->S;
+        const size_t ns = shadow_buffer_floats(ctx->S);
         hipLaunchKernelGGL(k_fill_f32, dim3((uint32_t)((ns + 255) / 256)), dim3(256), 0, ctx->stream, sf.d_shadow, ns, 1.0f);
     }
     if ((rc = begin_counted(ctx)) != WR_OK) return rc;

@@ -467,7 +467,22 @@ WR_HD V4 sample_material(const uint32_t* texels, const TexDesc& t, const ColorTa
 
 // ---------------------------------------------------------------------------------------
 // Shadow lookup: light.wgsl.
-struct ShadowMap { const float* data; int S; };
+// The six faces' depth, then, in the same buffer, (min, max) depth of every 8x8 texel tile of
+// every face (written with the faces by the shadow rasteriser): a lookup whose reference depth
+// is not above the minimum, or is above the maximum, of the tiles its taps can touch knows
+// every one of its compares without fetching a texel.
+constexpr int kShadowTile = 8;
+WR_HD int shadow_tiles_w(int S) { return (S + kShadowTile - 1) / kShadowTile; }
+WR_HD size_t shadow_buffer_floats(int S) {
+    return (size_t)6 * (size_t)S * (size_t)S + (size_t)12 * (size_t)shadow_tiles_w(S) * (size_t)shadow_tiles_w(S);
+}
+struct ShadowMap {
+    const float* data;
+    int S;
+    WR_HD const float* tiles(int layer) const {
+        return data + (size_t)6 * (size_t)S * (size_t)S + (size_t)2 * (size_t)layer * (size_t)shadow_tiles_w(S) * (size_t)shadow_tiles_w(S);
+    }
+};
 
 // textureSampleCompare with the sampler of texture.rs:59-72 (ClampToEdge, Linear,
 // compare LessEqual, state.rs:218): four compares, bilinear blend of the 0/1 results.
@@ -502,7 +517,30 @@ constexpr float kFogLightDensity = 3.0f;
 constexpr float kFogAlpha = 1.0f;
 constexpr float kFogDensityColorX = 0.5f, kFogDensityColorY = 0.1f;
 
-// light.wgsl:1-29.  The loops run x,y in [-2,2): 16 taps weighted 1/25 each.
+// One axis of textureSampleCompare's footprint for the four taps of the loops below: the
+// texel coordinate before clamping and the blend weight, worked out per tap exactly as
+// shadow_compare does.
+struct PcfAxis { int fl[4]; float fr[4]; };
+WR_HD PcfAxis pcf_axis(float centre, float S, float ts) {
+    PcfAxis a;
+    for (int k = 0; k < 4; ++k) {
+        float o = (float)(k - kShadowSamples) / ts;
+        float x = guard_coord((centre + o) * S - 0.5f);
+        float x0 = floorf(x);
+        a.fr[k] = x - x0;
+        a.fl[k] = (int)x0;
+    }
+    return a;
+}
+// light.wgsl:1-29.  The loops run x,y in [-2,2): 16 taps weighted 1/25 each.  The taps are one
+// texel apart, so their sixteen 2x2 footprints are, all but never, the sixteen 2x2 windows of
+// one 5x5 block of texels: that block is fetched and compared once (25 loads for 64), and each
+// tap blends its four results with its own weights in the order of the loops.  Whether the
+// footprints line up is checked on the tap coordinates themselves (rounding in (centre + o) * S
+// can shift a tap's floor); if they do not, every tap does its own lookups.
+// BLOCK = false always takes the tap-by-tap path: for kernels where the lookup is a small part
+// of the work and the block's registers would cost a resident wavefront.
+template <bool BLOCK>
 WR_HD float sample_direct_light_index(const ShadowMap& sm, int index, V4 lc) {
     if (lc.w <= 0.0f) return 0.0f;
     float pc = 1.0f / lc.w;
@@ -511,6 +549,53 @@ WR_HD float sample_direct_light_index(const ShadowMap& sm, int index, V4 lc) {
     float ref = lc.z * pc - 0.000001f;
     float total = 0.0f;
     float ts = (float)sm.S;
+    const PcfAxis ax = pcf_axis(lx, ts, ts), ay = pcf_axis(ly, ts, ts);
+    // texels the sixteen footprints can touch, after clamping: columns [c0, c1], rows [r0, r1]
+    int c0 = ax.fl[0], c1 = ax.fl[0], r0 = ay.fl[0], r1 = ay.fl[0];
+    for (int k = 1; k < 4; ++k) {
+        c0 = imin(c0, ax.fl[k]); c1 = imax(c1, ax.fl[k]);
+        r0 = imin(r0, ay.fl[k]); r1 = imax(r1, ay.fl[k]);
+    }
+    c0 = clampi(c0, sm.S); c1 = clampi(c1 + 1, sm.S); r0 = clampi(r0, sm.S); r1 = clampi(r1 + 1, sm.S);
+    if (c1 - c0 < kShadowTile && r1 - r0 < kShadowTile) {  // at most 2x2 tiles
+        const int tw = shadow_tiles_w(sm.S);
+        const float* T = sm.tiles(index);
+        const int tc0 = c0 / kShadowTile, tc1 = c1 / kShadowTile, tr0 = r0 / kShadowTile, tr1 = r1 / kShadowTile;
+        const float* a = T + 2 * ((size_t)tr0 * tw + tc0);
+        const float* b = T + 2 * ((size_t)tr0 * tw + tc1);
+        const float* c = T + 2 * ((size_t)tr1 * tw + tc0);
+        const float* d = T + 2 * ((size_t)tr1 * tw + tc1);
+        const float lo = fminf(fminf(a[0], b[0]), fminf(c[0], d[0])), hi = fmaxf(fmaxf(a[1], b[1]), fmaxf(c[1], d[1]));
+        // every compare `ref <= texel` fails: each tap blends four zeros, lerpf(0, 0, f) = 0 + f * 0
+        if (ref > hi) return 0.0f;
+        // every compare passes: each tap is lerpf(1, 1, f) = 1 + f * 0 = 1 (the weights are finite)
+        if (ref <= lo) {
+            for (int k = 0; k < 4 * kShadowSamples * kShadowSamples; ++k) total += 1.0f * kInvShadowSamples;
+            return total;
+        }
+    }
+    bool lined_up = BLOCK;
+    for (int k = 1; k < 4; ++k) lined_up = lined_up && ax.fl[k] == ax.fl[0] + k && ay.fl[k] == ay.fl[0] + k;
+    if (lined_up) {
+        const float* L = sm.data + (size_t)index * (size_t)sm.S * (size_t)sm.S;
+        int col[5];
+        size_t row[5];
+        for (int m = 0; m < 5; ++m) {
+            col[m] = clampi(ax.fl[0] + m, sm.S);
+            row[m] = (size_t)clampi(ay.fl[0] + m, sm.S) * (size_t)sm.S;
+        }
+        uint32_t pass = 0u;  // bit 5 * r + c: ref <= texel (row r, column c) of the block
+        for (int r = 0; r < 5; ++r)
+            for (int c = 0; c < 5; ++c) pass |= (ref <= L[row[r] + col[c]] ? 1u : 0u) << (5 * r + c);
+        for (int x = 0; x < 4; ++x)
+            for (int y = 0; y < 4; ++y) {
+                const uint32_t w = pass >> (5 * y + x);
+                float c00 = (float)(w & 1u), c10 = (float)((w >> 1) & 1u), c01 = (float)((w >> 5) & 1u), c11 = (float)((w >> 6) & 1u);
+                float s = lerpf(lerpf(c00, c10, ax.fr[x]), lerpf(c01, c11, ax.fr[x]), ay.fr[y]);
+                total += s * kInvShadowSamples;
+            }
+        return total;
+    }
     for (int x = -kShadowSamples; x < kShadowSamples; ++x)
         for (int y = -kShadowSamples; y < kShadowSamples; ++y) {
             float ox = (float)x / ts, oy = (float)y / ts;
@@ -521,6 +606,7 @@ WR_HD float sample_direct_light_index(const ShadowMap& sm, int index, V4 lc) {
 }
 
 // light.wgsl:31-61
+template <bool BLOCK = true>
 WR_HD float sample_direct_light(const FrameConsts& fc, const ShadowMap& sm, V4 wp) {
     float in_light = 0.0f;
     if (fc.use_shadowmaps > 0u) {
@@ -540,7 +626,7 @@ WR_HD float sample_direct_light(const FrameConsts& fc, const ShadowMap& sm, V4 w
             if (ld.z < kInvSqrt3 - 0.01f) continue;
             if (fabsf(ld.y) > kInvSqrt2 + 0.01f) continue;
             if (fabsf(ld.x) > kInvSqrt2 + 0.01f) continue;
-            in_light = sample_direct_light_index(sm, i, lc);
+            in_light = sample_direct_light_index<BLOCK>(sm, i, lc);
             if (in_light > 0.0f) break;
         }
     } else {
@@ -861,6 +947,7 @@ template <class NoiseAt>
 WR_HD V2 ray_march_stored(float max_depth, int max_steps, float step_size, float fog_density, NoiseAt noise_at, uint32_t& evals) {
     float density = 0.0f, depth = 0.0f;
     float contribution = fog_density / (float)max_steps;
+#pragma unroll
     for (int i = 0; i < max_steps; ++i) {
         depth += step_size;
         if (depth >= max_depth) break;
@@ -871,6 +958,17 @@ WR_HD V2 ray_march_stored(float max_depth, int max_steps, float step_size, float
     }
     return V2{density, depth};
 }
+// The stored noise of a march, fetched in one go: every step the depth exit allows has a value
+// (the density exit was not applied when they were written), so the loads do not depend on
+// the running sum and can all be in flight together; ray_march_stored then reads registers.
+template <int STEPS>
+struct StoredNoise {
+    float v[STEPS];
+    WR_HD void fetch(const float* column, size_t stride, float step_size, float max_depth) {
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) v[i] = step_size * (float)(i + 1) < max_depth ? column[(size_t)i * stride] : 0.0f;
+    }
+};
 // Value of `depth` in step i of ray_march (i from 0): step_size added i + 1 times to 0.  The
 // step sizes of constants.wgsl are the integers 5 and 10 and there are at most 30 steps, so
 // every partial sum is an integer below 2^24 and the product below is that sum exactly.
@@ -913,7 +1011,7 @@ WR_HD V4 fog_march_shade(const FrameConsts& fc, const ShadowMap& sm, const Noise
     V2 fm = ray_march(fc, nt, origin, direction, max_fog_depth, kFogMaxSteps, kFogStepSize, kFogDensity, evals);
     float fog_density = fm.x, fog_depth = fm.y;
     V3 fog_position = origin + direction * fog_depth;  // fog_end and fog_position of the shader are this one point
-    float in_light = sample_direct_light(fc, sm, V4{fog_position.x, fog_position.y, fog_position.z, 1.0f});
+    float in_light = sample_direct_light<false>(fc, sm, V4{fog_position.x, fog_position.y, fog_position.z, 1.0f});
     float occlusion = 0.0f;
     if (in_light > 0.0f) {
         // The light march (fog.wgsl:150-159) only feeds `occlusion`, which only the lit branch

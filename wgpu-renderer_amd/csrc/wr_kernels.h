@@ -552,6 +552,7 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
     __shared__ uint32_t bigq[kRasterThreads];  // record indices of the chunk's large triangles
     __shared__ uint32_t s_nbig;
     __shared__ unsigned long long s_fmask;  // layers: bit (8*by + bx) set = 8x8 block holds a flagged pixel
+    __shared__ uint32_t s_tmin[MODE == kRasterShadow ? 64 : 1], s_tmax[MODE == kRasterShadow ? 64 : 1];  // shadow: depth range per 8x8 tile
     const int b = blockIdx.x, layer = blockIdx.y;
 #ifdef WR_DEV
     const unsigned long long dbg_t0 = wall_clock64();
@@ -564,6 +565,7 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
         if (threadIdx.x == 0) s_fmask = 0ull;
         __syncthreads();
     }
+    if (MODE == kRasterShadow && threadIdx.x < 64) { s_tmin[threadIdx.x] = 0x7F7FFFFFu; s_tmax[threadIdx.x] = 0u; }
     for (int i = threadIdx.x; i < kBin * kBin; i += kRasterThreads) {
         if (MODE == kRasterShadow) tile32[i] = 0x3F800000u;
         else if (MODE == kRasterColor) tile[i] = 0x3F800000FFFFFFFFull;
@@ -693,14 +695,45 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
         __syncthreads();
     }
     __syncthreads();
+    if (MODE == kRasterShadow) {
+        // The face's texels, and the depth range of each 8x8 texel tile behind the faces (see
+        // ShadowMap): a wavefront holds one row of the bin, eight lanes one row of a tile.  Depths
+        // are in [0, 1], where the order of the floats is the order of their bits.
+        static_assert(kBin == 64 && kShadowTile == 8 && THREADS % 64 == 0, "one wavefront per bin row");
+        for (int i = threadIdx.x; i < kBin * kBin; i += kRasterThreads) {
+            const int x = i & (kBin - 1), y = i / kBin;
+            const int px = ox + x, py = oy + y;
+            const bool in = px < W && py < H;
+            const uint32_t zb = tile32[tile_index(x, y)];
+            if (in) depth[(size_t)layer * (size_t)W * (size_t)H + (size_t)py * W + px] = u2f(zb);
+            uint32_t lo = in ? zb : 0x7F7FFFFFu, hi = in ? zb : 0u;
+            for (int m = 1; m < 8; m <<= 1) {
+                lo = min(lo, (uint32_t)__shfl_xor((int)lo, m));
+                hi = max(hi, (uint32_t)__shfl_xor((int)hi, m));
+            }
+            if ((x & 7) == 0 && lo != 0x7F7FFFFFu) {
+                atomicMin(&s_tmin[(y >> 3) * 8 + (x >> 3)], lo);
+                atomicMax(&s_tmax[(y >> 3) * 8 + (x >> 3)], hi);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int tx = (ox >> 3) + (int)(threadIdx.x & 7u), ty = (oy >> 3) + (int)(threadIdx.x >> 3);
+            const int tw = shadow_tiles_w(W);
+            if (tx < tw && ty < shadow_tiles_w(H)) {
+                float* T = depth + (size_t)6 * (size_t)W * (size_t)H + 2 * ((size_t)layer * tw * tw + (size_t)ty * tw + tx);
+                T[0] = u2f(s_tmin[threadIdx.x]);
+                T[1] = u2f(s_tmax[threadIdx.x]);
+            }
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < kBin * kBin; i += kRasterThreads) {
         int px = ox + (i & (kBin - 1)), py = oy + (i / kBin);
         if (px >= W || py >= H) continue;
         size_t o = (size_t)layer * (size_t)W * (size_t)H + (size_t)py * W + px;
         const int ti = tile_index(i & (kBin - 1), i / kBin);
-        if (MODE == kRasterShadow) {
-            depth[o] = u2f(tile32[ti]);
-        } else if (MODE == kRasterLayers) {
+        if (MODE == kRasterLayers) {
             const uint32_t slot1 = (uint32_t)tile[ti];
             if (slot1 != 0u) ls.list_count[slot1 - 1u] = tile32[ti];
         } else {
@@ -1261,27 +1294,39 @@ __global__ __launch_bounds__(64) void k_fog_multi(FogArgs a) {
 }
 
 // Fills the hash tables: entry (i,j,k) of a level = hash of lattice point lo + (i,j,k).  The
-// workgroups of all levels form one grid.  A workgroup covers a tile of one z slice: 2^xshift
-// consecutive x (the power of two that holds the row, at most 256) by 256 >> xshift
+// workgroups of all levels form one grid.  A workgroup covers a tile of kTableSlices z slices:
+// 2^xshift consecutive x (the power of two that holds the row, at most 256) by 256 >> xshift
 // consecutive y, so narrow tables still fill their wavefronts and a thread decodes its index
-// with shifts only.
+// with shifts only; it then walks its column through the slices.  (One entry per thread made
+// the launch a matter of workgroup dispatch rate: 27000 workgroups of 0.1 us of work each.)
+constexpr int kTableSlices = 8;  // z slices one workgroup fills: a thread fills a column of that many entries
 struct TablePlan {
+    uint32_t fast_sine;     // bit l: every hash argument of level l is within the fast sine's range
     uint32_t wg_begin[17];  // first workgroup of each level (level l owns [wg_begin[l], wg_begin[l+1]))
     uint32_t xchunks[16];   // tiles per row = ceil(nx / 2^xshift)
     uint32_t ychunks[16];   // tiles per column = ceil(ny / (256 >> xshift))
     uint32_t xshift[16];
 };
-__host__ inline void plan_table_level(TablePlan& plan, int l, int nx, int ny, int nz) {
+__host__ inline void plan_table_level(TablePlan& plan, int l, const NoiseTable& t) {
     uint32_t sh = 0;
-    while (sh < 8 && (1u << sh) < (uint32_t)nx) ++sh;
+    while (sh < 8 && (1u << sh) < (uint32_t)t.nx) ++sh;
     const uint32_t xw = 1u << sh, yr = 256u >> sh;
     plan.xshift[l] = sh;
-    plan.xchunks[l] = ((uint32_t)nx + xw - 1u) / xw;
-    plan.ychunks[l] = ((uint32_t)ny + yr - 1u) / yr;
-    plan.wg_begin[l + 1] = plan.wg_begin[l] + plan.xchunks[l] * plan.ychunks[l] * (uint32_t)nz;
+    plan.xchunks[l] = ((uint32_t)t.nx + xw - 1u) / xw;
+    plan.ychunks[l] = ((uint32_t)t.ny + yr - 1u) / yr;
+    const uint32_t zchunks = ((uint32_t)t.nz + (uint32_t)kTableSlices - 1u) / (uint32_t)kTableSlices;
+    plan.wg_begin[l + 1] = plan.wg_begin[l] + plan.xchunks[l] * plan.ychunks[l] * zchunks;
+    // the largest hash argument of the level, with room for its three roundings
+    const double ax = std::max(std::abs((double)t.lox), std::abs((double)t.lox + t.nx));
+    const double ay = std::max(std::abs((double)t.loy), std::abs((double)t.loy + t.ny));
+    const double az = std::max(std::abs((double)t.loz), std::abs((double)t.loz + t.nz));
+    if ((ax * 12.345 + ay * 67.89 + az * 412.12) * 1.000001 < (double)kSinFastRange) plan.fast_sine |= 1u << l;
+}
+template <int TIER>
+__device__ inline void fill_table_column(float* out, size_t slice, float xy, int z0, int count) {
+    for (int k = 0; k < count; ++k) out[(size_t)k * slice] = hash_from_dot<TIER>(xy + (float)(z0 + k) * 412.12f);
 }
 __global__ __launch_bounds__(256) void k_fog_tables(NoiseTables nt, TablePlan plan) {
-    latency_bound_kernel();
     const uint32_t b = blockIdx.x;
     int level = 0;
     while (level < 15 && b >= plan.wg_begin[level + 1]) ++level;
@@ -1290,13 +1335,18 @@ __global__ __launch_bounds__(256) void k_fog_tables(NoiseTables nt, TablePlan pl
     const uint32_t local = b - plan.wg_begin[level];
     const uint32_t xc = local % plan.xchunks[level], rest = local / plan.xchunks[level];
     const uint32_t yc = rest % plan.ychunks[level];
-    const int iz = (int)(rest / plan.ychunks[level]);
+    const int iz0 = (int)(rest / plan.ychunks[level]) * kTableSlices;
     const uint32_t sh = plan.xshift[level];
     const int ix = (int)((xc << sh) + (threadIdx.x & ((1u << sh) - 1u)));
     const int iy = (int)(yc * (256u >> sh) + (threadIdx.x >> sh));
     if (ix >= t.nx || iy >= t.ny) return;
-    const size_t i = ((size_t)iz * t.ny + iy) * t.nx + ix;
-    const_cast<float*>(t.data)[i] = lattice_hash((float)(t.lox + ix), (float)(t.loy + iy), (float)(t.loz + iz));
+    const size_t slice = (size_t)t.nx * t.ny;
+    float* out = const_cast<float*>(t.data) + ((size_t)iz0 * t.ny + iy) * t.nx + ix;
+    // rand(u) of noise.wgsl:3-5 for the integer u = lo + (ix, iy, iz): (x*12.345 + y*67.89) + z*412.12
+    const float xy = (float)(t.lox + ix) * 12.345f + (float)(t.loy + iy) * 67.89f;
+    const int count = imin(kTableSlices, t.nz - iz0);
+    if ((plan.fast_sine >> level) & 1u) fill_table_column<kSinFast>(out, slice, xy, t.loz + iz0, count);
+    else fill_table_column<kSinGuarded>(out, slice, xy, t.loz + iz0, count);
 }
 
 // Fog pass, part 2: the marches of fog.wgsl:64-116, cut at their only sequential dependence.
@@ -1375,12 +1425,20 @@ __global__ __launch_bounds__(256) void k_fog_view_resolve(FogArgs a) {
         const V3 origin = v3(ray.x, ray.y, ray.z);
         const V3 dir = fog_item_dir(a.fc, origin);
         uint32_t evals = 0;
-        const float* nv = a.noise_view + k;
-        const size_t cap = a.cap;
-        fm = ray_march_stored(ray.w, kFogMaxSteps, kFogStepSize, kFogDensity, [nv, cap](int i) { return nv[(size_t)i * cap]; }, evals);
+#ifndef WR_DEV_RESOLVE_NOMARCH
+        StoredNoise<kFogMaxSteps> nv;
+        nv.fetch(a.noise_view + k, a.cap, kFogStepSize, ray.w);
+        fm = ray_march_stored(ray.w, kFogMaxSteps, kFogStepSize, kFogDensity, [&nv](int i) { return nv.v[i]; }, evals);
+#else
+        fm = V2{0.5f, fminf(ray.w, 50.0f)};
+#endif
         const V3 fp = origin + dir * fm.y;
         ShadowMap sm{a.shadow, a.fc.S};
+#ifndef WR_DEV_RESOLVE_NOSHADOW
         in_light = sample_direct_light(a.fc, sm, V4{fp.x, fp.y, fp.z, 1.0f});
+#else
+        in_light = fp.x > 0.0f ? 1.0f : 0.0f;
+#endif
         if (COUNT) atomicAdd(&a.counters[1], (unsigned long long)evals);
     }
     const bool lit = live && in_light > 0.0f;
@@ -1426,10 +1484,10 @@ __global__ __launch_bounds__(256) void k_fog_shade_blend(FogArgs a) {
         if (in_light > 0.0f) {
             const LightRay lr = fog_light_ray(a.fc, fp);
             uint32_t evals = 0;
-            const float* nl = a.noise_light + f2u(res.w);
-            const size_t cap = a.cap;
+            StoredNoise<kFogLightMaxSteps> nl;
+            nl.fetch(a.noise_light + f2u(res.w), a.cap, kFogLightStepSize, lr.max_dist);
             occlusion = ray_march_stored(lr.max_dist, kFogLightMaxSteps, kFogLightStepSize, kFogLightDensity,
-                                         [nl, cap](int i) { return nl[(size_t)i * cap]; }, evals).x;
+                                         [&nl](int i) { return nl.v[i]; }, evals).x;
             if (COUNT) atomicAdd(&a.counters[1], (unsigned long long)evals);
         }
         const V4 src = fog_shade(a.fc, fp, res.x, in_light, occlusion);
