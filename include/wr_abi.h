@@ -129,7 +129,7 @@ typedef struct WrConfig {
     /* Frames in flight (the reference's surface keeps more than one frame in flight as well,
      * state.rs:631,806).  0 or 1: a frame's work is complete, as seen from `stream`, before
      * anything queued on `stream` afterwards.  2 to 4: consecutive frames rotate through that
-     * many sets of frame buffers (about 1.1 GB each at 1080p) and overlap on the device; a
+     * many sets of frame buffers (about 1.5 GB each at 1080p) and overlap on the device; a
      * frame's results are complete after wr_sync (every wr_read_* and wr_get_stats syncs), and
      * read-back / wr_color_device_ptr refer to the most recently submitted frame. */
     uint32_t frames_in_flight;
