@@ -958,8 +958,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 // left without room in the item buffer, are queued for k_replay_slow.
 __global__ __launch_bounds__(256) void k_resolve(ShadeArgs a) {
     latency_bound_kernel();
-    __shared__ uint32_t cid[kReplayK][256];
-    __shared__ float cz[kReplayK][256];
     __shared__ uint32_t s_cnt, s_base;
     const int tid = threadIdx.x;
     const BlendWS& bw = a.bw;
@@ -969,39 +967,56 @@ __global__ __launch_bounds__(256) void k_resolve(ShadeArgs a) {
         const bool live = s < nslots;
         const uint32_t cnt = live ? bw.list_count[s] : 0u;
         bool slow = cnt > (uint32_t)kReplayK;
-        int np = 0, start = 0;
+        // The list lives in registers (the sort is a fixed network, every index a constant), so
+        // the kernel needs no LDS to speak of and its workgroups fit next to anything.
+        uint32_t id[kReplayK];
+        float z[kReplayK];
+        uint32_t keep = 0u;      // bit i: entry i of the sorted list passed the depth test when drawn
+        int first_kept = kReplayK;  // index of the entry the blending starts from
+        uint32_t want = 0u;
         if (live && !slow) {
-            // the whole list in flight at once, then insertion by ascending id = draw order
-            uint2 q[kReplayK];
-#pragma unroll
-            for (int i = 0; i < kReplayK; ++i) q[i] = (uint32_t)i < cnt ? bw.lists[(size_t)i * bw.cap + s] : make_uint2(0u, 0u);
+            // the whole list in flight at once; empty entries sort to the end
 #pragma unroll
             for (int i = 0; i < kReplayK; ++i) {
-                if ((uint32_t)i < cnt) {
-                    const uint32_t id = q[i].x;
-                    const float z = u2f(q[i].y);
-                    int j = i - 1;
-                    while (j >= 0 && cid[j][tid] > id) { cid[j + 1][tid] = cid[j][tid]; cz[j + 1][tid] = cz[j][tid]; --j; }
-                    cid[j + 1][tid] = id; cz[j + 1][tid] = z;
-                }
+                const uint2 q = (uint32_t)i < cnt ? bw.lists[(size_t)i * bw.cap + s] : make_uint2(0xFFFFFFFFu, 0u);
+                id[i] = q.x; z[i] = u2f(q.y);
             }
+            // ascending id = draw order: Batcher's odd-even merge sort for 16 keys (63 exchanges)
+            static_assert(kReplayK == 16, "the sorting network below is the one for 16 keys");
+#define CX(x, y)                                                                  \
+    {                                                                             \
+        const bool sw = id[x] > id[y];                                            \
+        const uint32_t ia = sw ? id[y] : id[x], ib = sw ? id[x] : id[y];          \
+        const float za = sw ? z[y] : z[x], zb = sw ? z[x] : z[y];                 \
+        id[x] = ia; id[y] = ib; z[x] = za; z[y] = zb;                             \
+    }
+            CX(0, 1) CX(2, 3) CX(4, 5) CX(6, 7) CX(8, 9) CX(10, 11) CX(12, 13) CX(14, 15)
+            CX(0, 2) CX(1, 3) CX(4, 6) CX(5, 7) CX(8, 10) CX(9, 11) CX(12, 14) CX(13, 15)
+            CX(1, 2) CX(5, 6) CX(9, 10) CX(13, 14) CX(0, 4) CX(1, 5) CX(2, 6) CX(3, 7)
+            CX(8, 12) CX(9, 13) CX(10, 14) CX(11, 15) CX(2, 4) CX(3, 5) CX(10, 12) CX(11, 13)
+            CX(1, 2) CX(3, 4) CX(5, 6) CX(9, 10) CX(11, 12) CX(13, 14) CX(0, 8) CX(1, 9)
+            CX(2, 10) CX(3, 11) CX(4, 12) CX(5, 13) CX(6, 14) CX(7, 15) CX(4, 8) CX(5, 9)
+            CX(6, 10) CX(7, 11) CX(2, 4) CX(3, 5) CX(6, 8) CX(7, 9) CX(10, 12) CX(11, 13)
+            CX(1, 2) CX(3, 4) CX(5, 6) CX(7, 8) CX(9, 10) CX(11, 12) CX(13, 14)
+#undef CX
+            // a running minimum over depth gives the fragments that passed depth test Less when drawn
             float d = 1.0f;
-            for (uint32_t i = 0; i < cnt; ++i) {
-                float z = cz[i][tid];
-                if (z < d) {
-                    d = z;
-                    cid[np][tid] = cid[i][tid];
-                    ++np;
+#pragma unroll
+            for (int i = 0; i < kReplayK; ++i)
+                if ((uint32_t)i < cnt && z[i] < d) { d = z[i]; keep |= 1u << i; }
+            // blending starts at the last kept fragment whose material cannot be translucent (it
+            // replaced everything under it), else at the first kept one
+            bool found = false;
+#pragma unroll
+            for (int i = kReplayK - 1; i >= 0; --i)
+                if (!found && ((keep >> i) & 1u)) {
+                    const uint32_t tri = id[i] >> 3;
+                    first_kept = i;
+                    if (tri >= a.ntris_geom || a.mats[a.tri_mat[tri]].opaque) found = true;
                 }
-            }
-            for (start = np - 1; start > 0; --start) {
-                uint32_t tri = cid[start][tid] >> 3;
-                if (tri >= a.ntris_geom || a.mats[a.tri_mat[tri]].opaque) break;
-            }
-            if (start < 0) start = 0;
+            want = (uint32_t)__builtin_popcount(keep >> (first_kept < kReplayK ? first_kept : 0)) * (keep ? 1u : 0u);
         }
         // room in the item buffer
-        const uint32_t want = (live && !slow) ? (uint32_t)(np - start) : 0u;
         const uint32_t first = group_append(&bw.counts[1], want, &s_cnt, &s_base);
         if ((unsigned long long)first + want > bw.frag_cap) slow = true;
         if (!live) continue;
@@ -1012,7 +1027,10 @@ __global__ __launch_bounds__(256) void k_resolve(ShadeArgs a) {
             bw.slot_frags[s] = make_uint2(0u, kSlotDone);
             continue;
         }
-        for (uint32_t k = 0; k < want; ++k) bw.frag_item[first + k] = make_uint2(s, cid[start + (int)k][tid]);
+        uint32_t k = 0;
+#pragma unroll
+        for (int i = 0; i < kReplayK; ++i)
+            if (i >= first_kept && ((keep >> i) & 1u)) bw.frag_item[first + k++] = make_uint2(s, id[i]);
         bw.slot_frags[s] = make_uint2(first, want);
     }
 }
