@@ -142,8 +142,8 @@ typedef struct WrContext WrContext;
  * over the (at most 128 most recent) frames rendered since wr_set_profiling(ctx, 1).  The
  * "counting mode" counters are those of the last wr_render_* call (summed over the poses of a
  * batch); a counted call waits on the device for the frames still in flight, so its counters
- * are its own.  The two *_bin_items counts are written by every frame: with several frames in
- * flight they are those of one of the most recent frames.  The shadow pass runs on a library-owned side stream next to
+ * are its own.  The two *_bin_items counts are those of the most recently submitted frame.
+ * The shadow pass runs on a library-owned side stream next to
  * the geometry pass, so ms_shadow and ms_geometry overlap, ms_shade includes any wait for the
  * shadow maps, and ms_total is the frame from first to last kernel, not the sum.  No
  * counterpart in the reference (timestamp_writes: None on every pass,
@@ -251,7 +251,9 @@ int wr_render_frame_static(WrContext* ctx, const WrCameraUniform* camera, const 
                            const WrGlobalUniforms* globals, uint32_t passes, void* device_color);
 
 /* Blocks until the context's stream is idle (surface_texture.present(), state.rs:806,
- * is the reference's end-of-frame point). */
+ * is the reference's end-of-frame point).  This is also where a frame that overflowed one of
+ * the library's lists is reported (WR_ERR_CAPACITY; the text names the frame by its number in
+ * submission order: each set of frame buffers has its own error word). */
 int wr_sync(WrContext* ctx);
 
 /* ------------------------------------------------------------------ results */

@@ -123,6 +123,7 @@ struct FrameRes {
     hipStream_t ms = nullptr, side = nullptr, fs = nullptr;
     hipEvent_t ev_fork = nullptr, ev_start = nullptr, ev_join = nullptr, ev_shadow_done = nullptr, ev_geom_done = nullptr, ev_done = nullptr;
     bool submitted = false;  // ev_done has been recorded
+    uint64_t serial = 0;     // number (from 1) of the last frame submitted to this set
     // d_shadow holds the cleared depth (1.0 everywhere), the value a frame without shadow passes
     // samples: as at allocation, until a shadow pass draws into it
     bool shadow_is_clear = true;
@@ -173,7 +174,11 @@ struct WrContext {
     uint32_t* d_gather_send = nullptr;  // bin-sharded contexts: this rank's packed bins
     uint32_t* d_gather_recv = nullptr;  // and, for the gathering rank, every rank's slot
     unsigned long long* d_counters = nullptr;
-    uint32_t* d_err = nullptr;  // [0] error bits, [1] geometry bin items, [2] shadow bin items, [3] fog (unused)
+    // Per set of frame buffers four words: [0] error bits, [1] geometry bin items, [2] shadow bin
+    // items, [3] fog (unused).  A set's words belong to the frames rendered on that set, so an
+    // overflow names its frame.
+    uint32_t* d_err = nullptr;
+    uint64_t frames_submitted = 0;
 
     bool profiling = false, counting = false;
     // Profiling keeps one set of stage-boundary events per frame in a ring; wr_get_stats
@@ -343,6 +348,9 @@ int alloc_frame_scene(WrContext* ctx, Arena& ar, FrameRes* f) {
     const uint32_t nvg = ctx->dev[WR_MODEL_GEOMETRY].nv, ntg = ctx->dev[WR_MODEL_GEOMETRY].ntris;
     const uint32_t ntl = ctx->dev[WR_MODEL_LIGHT_MARKER].ntris, ntf = ctx->dev[WR_MODEL_FOG_VOLUME].ntris;
     const size_t nvs = std::max<uint32_t>(nvg, 1);
+    // (a frame carved from the static buffer is not one of the context's sets: it reports on set 0)
+    const ptrdiff_t set = (f >= &ctx->fr[0] && f < &ctx->fr[WrContext::kMaxFrames]) ? f - &ctx->fr[0] : 0;
+    uint32_t* const err = ctx->d_err + 4 * set;
     WR_HIP(arena_take(ar, f->vout.clip, sizeof(float4) * nvs));
     WR_HIP(arena_take(ar, f->vout.v0, sizeof(float4) * nvs));
     WR_HIP(arena_take(ar, f->vout.v1, sizeof(float4) * nvs));
@@ -357,7 +365,7 @@ int alloc_frame_scene(WrContext* ctx, Arena& ar, FrameRes* f) {
         const int bx = (ctx->W + kBin - 1) / kBin, by = (ctx->H + kBin - 1) / kBin;
         const uint64_t items = 8u * (slots + ovf) + 64u * (uint64_t)(bx * by) + (1u << 20);
         if (slots + ovf > 0xFFFFFFF0ull || items > 0xFFFFFFF0ull) return fail(ctx, WR_ERR_UNSUPPORTED, "geometry too large for the 32-bit bin lists");
-        if ((rc = alloc_ws(ctx, ar, f->geom, (uint32_t)std::max<uint64_t>(slots, 1), (uint32_t)ovf, (uint32_t)items, bx, by, 1, ctx->d_err, ctx->d_err + 1)) != WR_OK) return rc;
+        if ((rc = alloc_ws(ctx, ar, f->geom, (uint32_t)std::max<uint64_t>(slots, 1), (uint32_t)ovf, (uint32_t)items, bx, by, 1, err, err + 1)) != WR_OK) return rc;
     }
     {
         const uint64_t slots = std::max(ntg, 1u);
@@ -365,11 +373,11 @@ int alloc_frame_scene(WrContext* ctx, Arena& ar, FrameRes* f) {
         const int bs = (ctx->S + kBin - 1) / kBin;
         const uint64_t items = 6u * (4u * slots + 64u * (uint64_t)(bs * bs) + (1u << 18));
         if (6 * (slots + ovf) > 0xFFFFFFF0ull || items > 0xFFFFFFF0ull) return fail(ctx, WR_ERR_UNSUPPORTED, "geometry too large for the 32-bit bin lists");
-        if ((rc = alloc_ws(ctx, ar, f->shadow, (uint32_t)slots, (uint32_t)ovf, (uint32_t)items, bs, bs, 6, ctx->d_err, ctx->d_err + 2)) != WR_OK) return rc;
+        if ((rc = alloc_ws(ctx, ar, f->shadow, (uint32_t)slots, (uint32_t)ovf, (uint32_t)items, bs, bs, 6, err, err + 2)) != WR_OK) return rc;
     }
     {
         const uint32_t slots = std::max(ntf, 1u);
-        if ((rc = alloc_ws(ctx, ar, f->fog, slots, slots * kMaxFan + 8, 8, 1, 1, 1, ctx->d_err, ctx->d_err + 3, 4)) != WR_OK) return rc;
+        if ((rc = alloc_ws(ctx, ar, f->fog, slots, slots * kMaxFan + 8, 8, 1, 1, 1, err, err + 3, 4)) != WR_OK) return rc;
     }
     return WR_OK;
 }
@@ -896,6 +904,7 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
 int finish_frame(WrContext* ctx, FrameRes* f) {
     WR_HIP(hipEventRecord(f->ev_done, f->ms));
     f->submitted = true;
+    f->serial = ++ctx->frames_submitted;
     if (ctx->nfr == 1) WR_HIP(hipStreamWaitEvent(ctx->stream, f->ev_done, 0));
     return WR_OK;
 }
@@ -992,8 +1001,8 @@ int wr_create(const WrConfig* config, WrContext** out_ctx) {
         WR_HIP(hipMemcpy(ctx->d_tables, tables, sizeof(tables), hipMemcpyHostToDevice));
         WR_HIP(hipMalloc(&ctx->d_counters, 8 * sizeof(unsigned long long)));
         WR_HIP(hipMemset(ctx->d_counters, 0, 8 * sizeof(unsigned long long)));
-        WR_HIP(hipMalloc(&ctx->d_err, 4 * sizeof(uint32_t)));
-        WR_HIP(hipMemset(ctx->d_err, 0, 4 * sizeof(uint32_t)));
+        WR_HIP(hipMalloc(&ctx->d_err, 4 * WrContext::kMaxFrames * sizeof(uint32_t)));
+        WR_HIP(hipMemset(ctx->d_err, 0, 4 * WrContext::kMaxFrames * sizeof(uint32_t)));
         size_t ns = shadow_buffer_floats((int)S);  // faces, then the depth range of their 8x8 tiles
         for (int k = 0; k < ctx->nfr; ++k) {
             FrameRes* f = &ctx->fr[k];
@@ -1214,14 +1223,22 @@ int wr_sync(WrContext* ctx) {
         int rcs = sync_all(ctx);
         if (rcs != WR_OK) return rcs;
     }
-    uint32_t e[4] = {0, 0, 0, 0};
+    uint32_t e[4 * WrContext::kMaxFrames] = {0};
     WR_HIP(hipMemcpy(e, ctx->d_err, sizeof(e), hipMemcpyDeviceToHost));
-    ctx->stats.geometry_bin_items = e[1];
-    ctx->stats.shadow_bin_items = e[2];
-    if (e[0]) {
-        WR_HIP(hipMemset(ctx->d_err, 0, sizeof(uint32_t)));
-        return fail(ctx, WR_ERR_CAPACITY,
-                    (e[0] & kErrClipOverflow) ? "clipped-triangle record capacity exceeded" : "bin item capacity exceeded");
+    ctx->stats.geometry_bin_items = e[4 * ctx->cur + 1];
+    ctx->stats.shadow_bin_items = e[4 * ctx->cur + 2];
+    // the earliest frame that overflowed a list
+    int bad = -1;
+    for (int k = 0; k < ctx->nfr; ++k)
+        if (e[4 * k] && (bad < 0 || ctx->fr[k].serial < ctx->fr[bad].serial)) bad = k;
+    if (bad >= 0) {
+        for (int k = 0; k < ctx->nfr; ++k) WR_HIP(hipMemset(ctx->d_err + 4 * k, 0, sizeof(uint32_t)));
+        char msg[256];
+        snprintf(msg, sizeof(msg), "%s capacity exceeded by frame %llu of this context (of %llu submitted), or by a frame %d, %d, ... "
+                                   "frames before it since the last wr_sync",
+                 (e[4 * bad] & kErrClipOverflow) ? "clipped-triangle record" : "bin item",
+                 (unsigned long long)ctx->fr[bad].serial, (unsigned long long)ctx->frames_submitted, ctx->nfr, 2 * ctx->nfr);
+        return fail(ctx, WR_ERR_CAPACITY, msg);
     }
     return WR_OK;
 }
