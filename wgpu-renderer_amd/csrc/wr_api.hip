@@ -551,11 +551,6 @@ int bin_and_raster(WrContext* ctx, FrameRes* f, hipStream_t st, WsAlloc& w, bool
 
 int shadow_stage(WrContext* ctx, FrameRes* f, hipStream_t st, const FrameConsts& fc) {
     const ModelDev& g = ctx->dev[WR_MODEL_GEOMETRY];
-    {
-        ClearList cl{};
-        cl.ptr[0] = f->shadow.counters; cl.words[0] = (uint32_t)(f->shadow.counters_bytes / 4);
-        hipLaunchKernelGGL(k_clear_words, dim3(32), dim3(256), 0, st, cl);
-    }
     hipLaunchKernelGGL(k_vs_shadow, grid1(g.nv, 6), dim3(256), 0, st, g.pos, g.nv, f->d_shadow_clip, fc);
     hipLaunchKernelGGL(k_setup<true>, grid1(g.ntris, 6), dim3(256), 0, st, f->d_shadow_clip, g.nv, g.idx, g.ntris,
                        f->shadow.ws, ctx->S, ctx->S, 0, 1);
@@ -712,7 +707,8 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
     const ModelDev& fm = ctx->dev[WR_MODEL_FOG_VOLUME];
     const bool prof = ctx->profiling;
     hipEvent_t* ev = ctx->ev[ctx->ev_next];
-    const bool latency_schedule = ctx->nfr == 1;
+    static const char* sched_env = getenv("WR_DEBUG_SCHEDULE");  // "split" / "mono": force a fog schedule
+    const bool latency_schedule = sched_env ? sched_env[0] == 's' : ctx->nfr == 1;
     hipStream_t ms = f->ms, ss = f->side, fs = latency_schedule ? f->fs : f->side;
     int rc;
     // order the frame after what the caller has queued on its stream so far
@@ -721,6 +717,16 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
     if (prof) WR_HIP(hipEventRecord(ev[0], ms));
     const bool fog_pass = (passes & WR_PASS_FOG) && fm.ntris;
 
+    // every counter block of the frame's three raster work spaces and of the ordered blending, in
+    // one launch, before the streams part
+    {
+        ClearList cl{};
+        cl.ptr[0] = f->geom.counters; cl.words[0] = (uint32_t)(f->geom.counters_bytes / 4);
+        cl.ptr[1] = f->blend.counts; cl.words[1] = (uint32_t)(f->blend_clear_bytes / 4);
+        cl.ptr[2] = f->shadow.counters; cl.words[2] = (uint32_t)(f->shadow.counters_bytes / 4);
+        cl.ptr[3] = f->fog.counters; cl.words[3] = (uint32_t)(f->fog.counters_bytes / 4);
+        hipLaunchKernelGGL(k_clear_words, dim3(32), dim3(256), 0, ms, cl);
+    }
     // after this set's previous frame and the caller's earlier work
     WR_HIP(hipEventRecord(f->ev_start, ms));
     WR_HIP(hipStreamWaitEvent(ss, f->ev_start, 0));
@@ -732,12 +738,6 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
     // overlapping: the shadow passes, the longer chain, which shading waits for).
     auto submit_geometry = [&]() -> int {
         // main stream: geometry + light marker -> visibility / depth
-        {
-            ClearList cl{};
-            cl.ptr[0] = f->geom.counters; cl.words[0] = (uint32_t)(f->geom.counters_bytes / 4);
-            cl.ptr[1] = f->blend.counts; cl.words[1] = (uint32_t)(f->blend_clear_bytes / 4);
-            hipLaunchKernelGGL(k_clear_words, dim3(8), dim3(256), 0, ms, cl);
-        }
         VertexIn vin{g.pos, g.uv, g.nrm, g.tan, g.bit, g.nv};
         hipLaunchKernelGGL(k_vs_geometry, grid1(g.nv), dim3(256), 0, ms, vin, f->vout, fc);
         hipLaunchKernelGGL(k_setup<false>, grid1(g.ntris, 1), dim3(256), 0, ms, f->vout.clip, g.nv, g.idx, g.ntris,
@@ -775,9 +775,6 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
     memset(&fa, 0, sizeof(fa));
     auto submit_fog_prologue = [&]() {
         if (fog_pass) {
-            ClearList cl{};
-            cl.ptr[0] = f->fog.counters; cl.words[0] = (uint32_t)(f->fog.counters_bytes / 4);
-            hipLaunchKernelGGL(k_clear_words, dim3(8), dim3(256), 0, fs, cl);
             hipLaunchKernelGGL(k_setup_small, grid1(fm.ntris), dim3(256), 0, fs, fm.pos, fm.idx, fm.ntris, 1, 1, 0u, f->fog.ws, fc);
             uint32_t max_entries = 0;
             fa.tables_noise = plan_noise_tables(ctx, f, fc, &max_entries);
