@@ -488,7 +488,7 @@ def test_error_paths():
 # ------------------------------------------------------------------ full size
 @pytest.fixture(scope="module")
 def full_scene():
-    return scene.sponza_standin(detail=1.0, tex_size=256)
+    return scene.sponza_standin(detail=1.0, tex_size=1024)  # the scene bench.py times
 
 
 def test_full_size_frame_against_oracle(full_scene):
