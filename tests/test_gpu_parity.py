@@ -462,6 +462,31 @@ def test_resize_and_scene_reuse(tiny_scene):
     r.close()
 
 
+def test_list_overflow_is_reported_with_its_frame(tiny_scene, monkeypatch):
+    """A frame whose bin item list overflows is reported at the next wr_sync, by its number in
+    submission order (each set of frame buffers has its own error word), and the context goes
+    on working."""
+    w, h, s = 256, 144, 128
+    cam, light, glob = default_inputs(w, h)
+    good = render_gpu(tiny_scene, cam, light, glob, abi.PASS_ALL, w, h, s)["color"]
+    monkeypatch.setenv("WR_DEBUG_BIN_ITEMS_CAP", "100")
+    r = abi.Renderer(w, h, s, frames_in_flight=2)
+    r.upload_scene(tiny_scene)
+    for _ in range(3):
+        r.render_frame(cam, light, glob, abi.PASS_ALL)
+    with pytest.raises(abi.WrError) as e:
+        r.sync()
+    assert e.value.code == abi.WR_ERR_CAPACITY and "bin item capacity exceeded by frame 2 " in str(e.value), str(e.value)
+    r.sync()  # reported once
+    r.render_frame(cam, light, glob, abi.PASS_ALL)
+    with pytest.raises(abi.WrError) as e:
+        r.read_color()
+    assert "by frame 4 " in str(e.value), str(e.value)
+    r.close()
+    monkeypatch.delenv("WR_DEBUG_BIN_ITEMS_CAP")
+    assert np.array_equal(render_gpu(tiny_scene, cam, light, glob, abi.PASS_ALL, w, h, s)["color"], good)
+
+
 def test_error_paths():
     r = abi.Renderer(64, 64, 64)
     cam, light, glob = default_inputs(64, 64)

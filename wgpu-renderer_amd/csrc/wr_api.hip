@@ -363,7 +363,10 @@ int alloc_frame_scene(WrContext* ctx, Arena& ar, FrameRes* f) {
         const uint64_t slots = (uint64_t)ntg + ntl;
         const uint64_t ovf = slots / 2 + 8192;
         const int bx = (ctx->W + kBin - 1) / kBin, by = (ctx->H + kBin - 1) / kBin;
-        const uint64_t items = 8u * (slots + ovf) + 64u * (uint64_t)(bx * by) + (1u << 20);
+        uint64_t items = 8u * (slots + ovf) + 64u * (uint64_t)(bx * by) + (1u << 20);
+        // Test aid: WR_DEBUG_BIN_ITEMS_CAP shrinks the geometry pass's bin item list, so that the
+        // overflow report (wr_sync) can be exercised; every write to the list is bounds-checked.
+        if (const char* cap_env = getenv("WR_DEBUG_BIN_ITEMS_CAP")) items = std::min<uint64_t>(items, (uint64_t)std::max(atoll(cap_env), 1ll));
         if (slots + ovf > 0xFFFFFFF0ull || items > 0xFFFFFFF0ull) return fail(ctx, WR_ERR_UNSUPPORTED, "geometry too large for the 32-bit bin lists");
         if ((rc = alloc_ws(ctx, ar, f->geom, (uint32_t)std::max<uint64_t>(slots, 1), (uint32_t)ovf, (uint32_t)items, bx, by, 1, err, err + 1)) != WR_OK) return rc;
     }
