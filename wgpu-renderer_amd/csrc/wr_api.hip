@@ -122,6 +122,7 @@ struct FrameRes {
     // tables, then (once the geometry depth exists) the marches, next to the shading kernels.
     hipStream_t ms = nullptr, side = nullptr, fs = nullptr;
     hipEvent_t ev_fork = nullptr, ev_start = nullptr, ev_join = nullptr, ev_shadow_done = nullptr, ev_geom_done = nullptr, ev_done = nullptr;
+    hipEvent_t ev_prologue_done = nullptr;  // fog volume set-up and noise tables done (one frame in flight)
     bool submitted = false;  // ev_done has been recorded
     uint64_t serial = 0;     // number (from 1) of the last frame submitted to this set
     // d_shadow holds the cleared depth (1.0 everywhere), the value a frame without shadow passes
@@ -802,8 +803,21 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
         if ((rc = submit_geometry()) != WR_OK) return rc;
         submit_fog_prologue();
     }
-    WR_HIP(hipStreamWaitEvent(fs, f->ev_geom_done, 0));
-    if (prof) WR_HIP(hipEventRecord(ev[8], fs));
+    // One frame in flight: the frame's critical path is geometry -> fog set-up -> marches -> fog
+    // blend, so those stay on ONE stream (the main one; a wait across streams costs 10-25 us each
+    // time) and the shading kernels, which have slack, move to the fog stream once it has done the
+    // fog volume set-up and the tables.  Frames overlapping: the fog pass follows the shadow
+    // passes on the side stream, shading stays on the main stream.
+    const bool swap_roles = latency_schedule && fs != ms;
+    hipStream_t fog_st = swap_roles ? ms : fs, shade_st = swap_roles ? fs : ms;
+    if (swap_roles) {
+        WR_HIP(hipEventRecord(f->ev_prologue_done, fs));
+        WR_HIP(hipStreamWaitEvent(ms, f->ev_prologue_done, 0));
+        WR_HIP(hipStreamWaitEvent(fs, f->ev_geom_done, 0));
+    } else {
+        WR_HIP(hipStreamWaitEvent(fs, f->ev_geom_done, 0));
+    }
+    if (prof) WR_HIP(hipEventRecord(ev[8], fog_st));
     const size_t npx = (size_t)ctx->W * ctx->H;
     const uint32_t item_groups = (uint32_t)((npx + 255) / 256);
     if (fog_pass) {
@@ -819,41 +833,41 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
         fa.item_res = f->d_fog_res; fa.noise_view = f->d_fog_noise_view; fa.noise_light = f->d_fog_noise_light;
         fa.cap = (uint32_t)npx;
         dim3 fg((uint32_t)(ctx->W + kFogBlock - 1) / kFogBlock, (uint32_t)(ctx->H + kFogBlock - 1) / kFogBlock, 1);
-        if (ctx->counting) hipLaunchKernelGGL(k_fog_setup<true>, fg, dim3(1024), 0, fs, fa);
-        else hipLaunchKernelGGL(k_fog_setup<false>, fg, dim3(1024), 0, fs, fa);
-        if (prof) WR_HIP(hipEventRecord(ev[6], fs));
+        if (ctx->counting) hipLaunchKernelGGL(k_fog_setup<true>, fg, dim3(1024), 0, fog_st, fa);
+        else hipLaunchKernelGGL(k_fog_setup<false>, fg, dim3(1024), 0, fog_st, fa);
+        if (prof) WR_HIP(hipEventRecord(ev[6], fog_st));
         if (latency_schedule) {
             const dim3 vg(item_groups * (uint32_t)kFogViewGroups, 1, 1);
-            if (ctx->counting) hipLaunchKernelGGL(k_fog_noise_view<true>, vg, dim3(256), 0, fs, fa);
-            else hipLaunchKernelGGL(k_fog_noise_view<false>, vg, dim3(256), 0, fs, fa);
-            if (prof) WR_HIP(hipEventRecord(ev[9], fs));
-            WR_HIP(hipStreamWaitEvent(fs, f->ev_shadow_done, 0));
-            if (ctx->counting) hipLaunchKernelGGL(k_fog_view_resolve<true>, dim3(item_groups), dim3(256), 0, fs, fa);
-            else hipLaunchKernelGGL(k_fog_view_resolve<false>, dim3(item_groups), dim3(256), 0, fs, fa);
-            if (prof) WR_HIP(hipEventRecord(ev[10], fs));
+            if (ctx->counting) hipLaunchKernelGGL(k_fog_noise_view<true>, vg, dim3(256), 0, fog_st, fa);
+            else hipLaunchKernelGGL(k_fog_noise_view<false>, vg, dim3(256), 0, fog_st, fa);
+            if (prof) WR_HIP(hipEventRecord(ev[9], fog_st));
+            WR_HIP(hipStreamWaitEvent(fog_st, f->ev_shadow_done, 0));
+            if (ctx->counting) hipLaunchKernelGGL(k_fog_view_resolve<true>, dim3(item_groups), dim3(256), 0, fog_st, fa);
+            else hipLaunchKernelGGL(k_fog_view_resolve<false>, dim3(item_groups), dim3(256), 0, fog_st, fa);
+            if (prof) WR_HIP(hipEventRecord(ev[10], fog_st));
 #ifdef WR_DEV
             for (int l = 0; l < 16; ++l) fa.tables_noise.level[l].dbg_level = 256 + l;
 #endif
             const dim3 lg(item_groups * (uint32_t)kFogLightGroups, 1, 1);
-            if (ctx->counting) hipLaunchKernelGGL(k_fog_noise_light<true>, lg, dim3(256), 0, fs, fa);
-            else hipLaunchKernelGGL(k_fog_noise_light<false>, lg, dim3(256), 0, fs, fa);
+            if (ctx->counting) hipLaunchKernelGGL(k_fog_noise_light<true>, lg, dim3(256), 0, fog_st, fa);
+            else hipLaunchKernelGGL(k_fog_noise_light<false>, lg, dim3(256), 0, fog_st, fa);
         } else {
             // (the side stream has the shadow maps: it rendered them)
             const dim3 mg((uint32_t)((npx + 63) / 64), 1, 1);
-            if (ctx->counting) hipLaunchKernelGGL(k_fog_march<true>, mg, dim3(64), 0, fs, fa);
-            else hipLaunchKernelGGL(k_fog_march<false>, mg, dim3(64), 0, fs, fa);
-            if (prof) { WR_HIP(hipEventRecord(ev[9], fs)); WR_HIP(hipEventRecord(ev[10], fs)); }
+            if (ctx->counting) hipLaunchKernelGGL(k_fog_march<true>, mg, dim3(64), 0, fog_st, fa);
+            else hipLaunchKernelGGL(k_fog_march<false>, mg, dim3(64), 0, fog_st, fa);
+            if (prof) { WR_HIP(hipEventRecord(ev[9], fog_st)); WR_HIP(hipEventRecord(ev[10], fog_st)); }
         }
     } else if (prof) {
-        WR_HIP(hipEventRecord(ev[6], fs));
-        WR_HIP(hipEventRecord(ev[9], fs));
-        WR_HIP(hipEventRecord(ev[10], fs));
+        WR_HIP(hipEventRecord(ev[6], fog_st));
+        WR_HIP(hipEventRecord(ev[9], fog_st));
+        WR_HIP(hipEventRecord(ev[10], fog_st));
     }
-    if (prof) WR_HIP(hipEventRecord(ev[5], fs));
-    WR_HIP(hipEventRecord(f->ev_join, fs));
+    if (prof) WR_HIP(hipEventRecord(ev[5], fog_st));
+    if (!swap_roles) WR_HIP(hipEventRecord(f->ev_join, fog_st));  // what the main stream waits for before the fog blend:
 
-    // main stream: shading (reads the shadow maps)
-    WR_HIP(hipStreamWaitEvent(ms, f->ev_shadow_done, 0));
+    // shading (reads the shadow maps; on another stream than the geometry pass it also waits for that)
+    WR_HIP(hipStreamWaitEvent(shade_st, f->ev_shadow_done, 0));
     ShadeArgs sa;
     sa.fc = fc; sa.ws = f->geom.ws; sa.vis = f->d_vis; sa.depth = f->d_depth; sa.color = f->d_color;
     sa.idx = g.idx; sa.tri_mat = g.tri_mat; sa.ntris_geom = g.ntris;
@@ -862,22 +876,23 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
     sa.shadow = f->d_shadow; sa.counters = ctx->d_counters;
     sa.bw = f->blend;
     dim3 pg((uint32_t)(ctx->W + 15) / 16, (uint32_t)(ctx->H + 15) / 16, 1);
-    if (ctx->counting) hipLaunchKernelGGL(k_shade<true>, pg, dim3(256), 0, ms, sa);
-    else hipLaunchKernelGGL(k_shade<false>, pg, dim3(256), 0, ms, sa);
+    if (ctx->counting) hipLaunchKernelGGL(k_shade<true>, pg, dim3(256), 0, shade_st, sa);
+    else hipLaunchKernelGGL(k_shade<false>, pg, dim3(256), 0, shade_st, sa);
     // ordered blending of the pixels k_shade flagged: collect, order, shade, blend
     {
         const RasterWS& ws = f->geom.ws;
         LayerSink ls{f->blend.rp_slot, f->d_vis, f->blend.bin_flag, f->blend.lists, f->blend.list_count, f->blend.cap};
         hipLaunchKernelGGL((k_raster<kRasterLayers, kColorRasterThreads>), dim3((uint32_t)(ws.bins_x * ws.bins_y), 1, 1), dim3(kColorRasterThreads), 0,
-                           ms, ws, ctx->W, ctx->H, (uint32_t*)nullptr, (float*)nullptr, fc.tile_rank, fc.tile_world, ls);
+                           shade_st, ws, ctx->W, ctx->H, (uint32_t*)nullptr, (float*)nullptr, fc.tile_rank, fc.tile_world, ls);
         const uint32_t slot_groups = (uint32_t)std::min<size_t>((npx + 255) / 256, 2048);
-        hipLaunchKernelGGL(k_resolve, dim3(slot_groups), dim3(256), 0, ms, sa);
-        if (ctx->counting) hipLaunchKernelGGL(k_replay_slow<true>, dim3(256), dim3(64), 0, ms, sa);
-        else hipLaunchKernelGGL(k_replay_slow<false>, dim3(256), dim3(64), 0, ms, sa);
-        hipLaunchKernelGGL(k_shade_frags, dim3((uint32_t)std::min<size_t>((npx + 63) / 64, 16384)), dim3(64), 0, ms, sa);
-        hipLaunchKernelGGL(k_blend, dim3(slot_groups), dim3(256), 0, ms, sa);
+        hipLaunchKernelGGL(k_resolve, dim3(slot_groups), dim3(256), 0, shade_st, sa);
+        if (ctx->counting) hipLaunchKernelGGL(k_replay_slow<true>, dim3(256), dim3(64), 0, shade_st, sa);
+        else hipLaunchKernelGGL(k_replay_slow<false>, dim3(256), dim3(64), 0, shade_st, sa);
+        hipLaunchKernelGGL(k_shade_frags, dim3((uint32_t)std::min<size_t>((npx + 63) / 64, 16384)), dim3(64), 0, shade_st, sa);
+        hipLaunchKernelGGL(k_blend, dim3(slot_groups), dim3(256), 0, shade_st, sa);
     }
-    if (prof) WR_HIP(hipEventRecord(ev[4], ms));
+    if (prof) WR_HIP(hipEventRecord(ev[4], shade_st));
+    if (swap_roles) WR_HIP(hipEventRecord(f->ev_join, shade_st));  // the fog pass, or (roles swapped) the shading
 
     // main stream: fog colours over the finished geometry colour
     WR_HIP(hipStreamWaitEvent(ms, f->ev_join, 0));
@@ -992,7 +1007,7 @@ int wr_create(const WrConfig* config, WrContext** out_ctx) {
                 WR_HIP(hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
                 WR_HIP(hipStreamCreateWithFlags(&f->fs, hipStreamNonBlocking));
             }
-            hipEvent_t* evs[] = {&f->ev_fork, &f->ev_start, &f->ev_join, &f->ev_shadow_done, &f->ev_geom_done, &f->ev_done};
+            hipEvent_t* evs[] = {&f->ev_fork, &f->ev_start, &f->ev_join, &f->ev_shadow_done, &f->ev_geom_done, &f->ev_done, &f->ev_prologue_done};
             for (hipEvent_t* e : evs) WR_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         }
         float tables[768];
@@ -1039,7 +1054,7 @@ void wr_destroy(WrContext* ctx) {
         if (f.ms) (void)hipStreamDestroy(f.ms);
         if (f.side && f.side != f.ms) (void)hipStreamDestroy(f.side);
         if (f.fs && f.fs != f.ms && f.fs != f.side) (void)hipStreamDestroy(f.fs);
-        hipEvent_t evs[] = {f.ev_fork, f.ev_start, f.ev_join, f.ev_shadow_done, f.ev_geom_done, f.ev_done};
+        hipEvent_t evs[] = {f.ev_fork, f.ev_start, f.ev_join, f.ev_shadow_done, f.ev_geom_done, f.ev_done, f.ev_prologue_done};
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1164,6 +1179,7 @@ int wr_render_frame_static(WrContext* ctx, const WrCameraUniform* camera, const 
     sf.ms = own.ms; sf.side = own.side; sf.fs = own.fs;
     sf.ev_fork = own.ev_fork; sf.ev_start = own.ev_start; sf.ev_join = own.ev_join;
     sf.ev_shadow_done = own.ev_shadow_done; sf.ev_geom_done = own.ev_geom_done; sf.ev_done = own.ev_done;
+    sf.ev_prologue_done = own.ev_prologue_done;
     Arena sizing;
     sizing.dry = true;
     if ((rc = carve_static_frame(ctx, sizing, &sf)) != WR_OK) return rc;
