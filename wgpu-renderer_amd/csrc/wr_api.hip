@@ -833,8 +833,8 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
         fa.item_res = f->d_fog_res; fa.noise_view = f->d_fog_noise_view; fa.noise_light = f->d_fog_noise_light;
         fa.cap = (uint32_t)npx;
         dim3 fg((uint32_t)(ctx->W + kFogBlock - 1) / kFogBlock, (uint32_t)(ctx->H + kFogBlock - 1) / kFogBlock, 1);
-        if (ctx->counting) hipLaunchKernelGGL(k_fog_setup<true>, fg, dim3(1024), 0, fog_st, fa);
-        else hipLaunchKernelGGL(k_fog_setup<false>, fg, dim3(1024), 0, fog_st, fa);
+        if (ctx->counting) hipLaunchKernelGGL(k_fog_setup<true>, fg, dim3(kFogSetupThreads), 0, fog_st, fa);
+        else hipLaunchKernelGGL(k_fog_setup<false>, fg, dim3(kFogSetupThreads), 0, fog_st, fa);
         if (prof) WR_HIP(hipEventRecord(ev[6], fog_st));
         if (latency_schedule) {
             const dim3 vg(item_groups * (uint32_t)kFogViewGroups, 1, 1);

@@ -1164,8 +1164,10 @@ struct StagedRec {
 };
 static_assert(sizeof(StagedRec) == 88, "StagedRec layout");
 
-// Fog pass, part 1 (state.rs:763-804): rasterises the fog volume per pixel.  A workgroup
-// owns a 32x32 pixel block: its threads first fetch the volume's records, one each, and
+// Fog pass, part 1 (state.rs:763-804): rasterises the fog volume per pixel.  A workgroup of 256
+// threads owns a 32x32 pixel block (four wavefronts find room on a busy device long before the
+// sixteen of a thread per pixel do, and one list append per block is all the single-address
+// atomics the launch can afford): its threads first fetch the volume's records, one each, and
 // stage those that can touch the block in LDS (edge set-up done once per record, not once
 // per pixel); then every pixel tests the staged records.  A pixel with exactly one fog
 // fragment (always the case for a convex volume) whose march is not empty becomes a work
@@ -1173,33 +1175,44 @@ static_assert(sizeof(StagedRec) == 88, "StagedRec layout");
 // fragments is queued for k_fog_multi.  Reads the geometry depth only, not the colour, so the
 // fog pass up to and including the march can run next to the shading kernels.
 constexpr int kFogBlock = 32;
+constexpr int kFogSetupThreads = 256;  // a thread takes a 2x2 pixel quad
 template <bool COUNT>
-__global__ __launch_bounds__(1024) void k_fog_setup(FogArgs a) {
+__global__ __launch_bounds__(kFogSetupThreads) void k_fog_setup(FogArgs a) {
     latency_bound_kernel();
     __shared__ StagedRec srec[256];
     __shared__ uint32_t s_m, s_cnt, s_base;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int bx0 = blockIdx.x * kFogBlock, by0 = blockIdx.y * kFogBlock;
-    const int px = bx0 + (wave & 3) * 8 + (lane & 7);
-    const int py = by0 + (wave >> 2) * 8 + (lane >> 3);
+    // A wavefront owns a 16x16 quadrant of the block; its lanes go through the quadrant's four 8x8
+    // tiles one after the other, sixteen lanes (4x4 quads) per tile, so that items appended in
+    // lane order keep the pixels of a tile together: 64 consecutive items are one 8x8 tile.
+    const int tile = lane >> 4, quad = lane & 15;
+    const int qx = bx0 + (wave & 1) * 16 + (tile & 1) * 8 + (quad & 3) * 2;
+    const int qy = by0 + (wave >> 1) * 16 + (tile >> 1) * 8 + (quad >> 2) * 2;
     if (a.fc.tile_world > 1) {  // a block lies in one bin
         int b = (by0 / kBin) * ((a.fc.W + kBin - 1) / kBin) + (bx0 / kBin);
         if ((b % a.fc.tile_world) != a.fc.tile_rank) return;
     }
-    const bool live = px < a.fc.W && py < a.fc.H;
     const int bx1 = imin(bx0 + kFogBlock - 1, a.fc.W - 1), by1 = imin(by0 + kFogBlock - 1, a.fc.H - 1);
-    const size_t pi = (size_t)py * a.fc.W + px;
-    const float zbuf = live ? a.depth[pi] : 0.0f;
-    const int32_t sx = px * 256 + 128, sy = py * 256 + 128;
+    bool live[4];
+    float zbuf[4];
+    int nfrag[4];
+    uint32_t hit_ri[4];
+    int64_t hit_E[4][3];
+    float hit_z[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int px = qx + (p & 1), py = qy + (p >> 1);
+        live[p] = px < a.fc.W && py < a.fc.H;
+        zbuf[p] = live[p] ? a.depth[(size_t)py * a.fc.W + px] : 0.0f;
+        nfrag[p] = 0; hit_ri[p] = 0u; hit_z[p] = 0.0f;
+        hit_E[p][0] = hit_E[p][1] = hit_E[p][2] = 0;
+    }
     const uint32_t nrec = a.ws.slots + min(a.ws.ovf_count[0], a.ws.ovf_cap);
-    int nfrag = 0;
-    uint32_t hit_ri = 0;
-    int64_t hit_E[3] = {0, 0, 0};
-    float hit_z = 0.0f;
     for (uint32_t c0 = 0; c0 < nrec; c0 += 256) {
         if (tid == 0) s_m = 0;
         __syncthreads();
-        if (tid < 256 && c0 + tid < nrec) {
+        if (c0 + tid < nrec) {
             const Rec* rp = &a.ws.recs[c0 + tid];
             const uint2 bb = a.ws.bb[c0 + tid];
             const uint32_t bbmin = bb.x, bbmax = bb.y;
@@ -1219,10 +1232,15 @@ __global__ __launch_bounds__(1024) void k_fog_setup(FogArgs a) {
         }
         __syncthreads();
         const int m = (int)s_m;
-        if (live) {
-            for (int j = 0; j < m; ++j) {
-                const StagedRec& q = srec[j];
-                if (px < (int)(q.bbmin & 0xffffu) || px > (int)(q.bbmax & 0xffffu) || py < (int)(q.bbmin >> 16) || py > (int)(q.bbmax >> 16)) continue;
+        for (int j = 0; j < m; ++j) {
+            const StagedRec& q = srec[j];
+            // the quad against the record's box
+            if (qx + 1 < (int)(q.bbmin & 0xffffu) || qx > (int)(q.bbmax & 0xffffu) || qy + 1 < (int)(q.bbmin >> 16) || qy > (int)(q.bbmax >> 16)) continue;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int px = qx + (p & 1), py = qy + (p >> 1);
+                if (!live[p] || px < (int)(q.bbmin & 0xffffu) || px > (int)(q.bbmax & 0xffffu) || py < (int)(q.bbmin >> 16) || py > (int)(q.bbmax >> 16)) continue;
+                const int32_t sx = px * 256 + 128, sy = py * 256 + 128;
                 int64_t E0 = (int64_t)q.A[0] * sx + (int64_t)q.B[0] * sy + q.C[0];
                 int64_t E1 = (int64_t)q.A[1] * sx + (int64_t)q.B[1] * sy + q.C[1];
                 int64_t E2 = (int64_t)q.A[2] * sx + (int64_t)q.B[2] * sy + q.C[2];
@@ -1230,43 +1248,56 @@ __global__ __launch_bounds__(1024) void k_fog_setup(FogArgs a) {
                 float l1 = (float)E1 * q.inv2A, l2 = (float)E2 * q.inv2A;
                 float z = (q.z0 + l1 * q.dz1) + l2 * q.dz2;
                 z = fminf(fmaxf(z, 0.0f), 1.0f);
-                if (!(z < zbuf)) continue;  // depth test Less, no depth write (state.rs:497-502)
-                hit_ri = q.ri; hit_E[0] = E0; hit_E[1] = E1; hit_E[2] = E2; hit_z = z;
-                if ((q.id >> 3) < a.ntris) ++nfrag;  // (always true for records written this frame)
+                if (!(z < zbuf[p])) continue;  // depth test Less, no depth write (state.rs:497-502)
+                hit_ri[p] = q.ri; hit_E[p][0] = E0; hit_E[p][1] = E1; hit_E[p][2] = E2; hit_z[p] = z;
+                if ((q.id >> 3) < a.ntris) ++nfrag[p];  // (always true for records written this frame)
             }
         }
         __syncthreads();
     }
-    V3 origin = v3(0.0f, 0.0f, 0.0f);
-    float max_depth = 0.0f;
-    if (nfrag == 1) {
-        // the pre-march part of fog.wgsl's fs_main on the interpolated world position
-        Rec r = load_rec(&a.ws.recs[hit_ri]);
-        const float* beta = hit_ri >= a.ws.slots ? a.ws.betas + (size_t)(hit_ri - a.ws.slots) * 9 : nullptr;
-        float B[3];
-        bary_at(r, beta, hit_E, B);
-        const uint32_t tri = r.id >> 3;
-        V4 w[3];
-        for (int k = 0; k < 3; ++k) {
-            float4 p = a.pos[a.idx[3 * tri + k]];
-            w[k] = mat4_mul(a.fc.model_fog, V4{p.x, p.y, p.z, 1.0f});
+    V3 origin[4];
+    float max_depth[4];
+    uint32_t want = 0u, multi = 0u, single = 0u;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        origin[p] = v3(0.0f, 0.0f, 0.0f);
+        max_depth[p] = 0.0f;
+        if (nfrag[p] == 1) {
+            // the pre-march part of fog.wgsl's fs_main on the interpolated world position
+            Rec r = load_rec(&a.ws.recs[hit_ri[p]]);
+            const float* beta = hit_ri[p] >= a.ws.slots ? a.ws.betas + (size_t)(hit_ri[p] - a.ws.slots) * 9 : nullptr;
+            float B[3];
+            bary_at(r, beta, hit_E[p], B);
+            const uint32_t tri = r.id >> 3;
+            V4 w[3];
+            for (int k = 0; k < 3; ++k) {
+                float4 v = a.pos[a.idx[3 * tri + k]];
+                w[k] = mat4_mul(a.fc.model_fog, V4{v.x, v.y, v.z, 1.0f});
+            }
+            origin[p] = v3(ip(B, w[0].x, w[1].x, w[2].x), ip(B, w[0].y, w[1].y, w[2].y), ip(B, w[0].z, w[1].z, w[2].z));
+            max_depth[p] = fog_max_depth(a.fc, a.depth, hit_z[p], qx + (p & 1), qy + (p >> 1));
+            ++single;
         }
-        origin = v3(ip(B, w[0].x, w[1].x, w[2].x), ip(B, w[0].y, w[1].y, w[2].y), ip(B, w[0].z, w[1].z, w[2].z));
-        max_depth = fog_max_depth(a.fc, a.depth, hit_z, px, py);
+        if (nfrag[p] == 1 && max_depth[p] > 0.0f) ++want;
+        if (nfrag[p] >= 2) ++multi;
     }
-    if (COUNT && nfrag == 1) atomicAdd(&a.counters[0], 1ull);
-    const bool item = nfrag == 1 && max_depth > 0.0f;
-    if (__syncthreads_or(nfrag >= 2 ? 1 : 0)) {
+    if (COUNT && single) atomicAdd(&a.counters[0], (unsigned long long)single);
+    if (__syncthreads_or(multi ? 1 : 0)) {
         // several fog fragments on one pixel (a fog volume that is not convex): left to k_fog_multi
-        const uint32_t m = group_append(a.multi_count, nfrag >= 2 ? 1u : 0u, &s_cnt, &s_base);
-        if (nfrag >= 2) a.multi_pixel[m] = (uint32_t)pi;
+        uint32_t m = group_append(a.multi_count, multi, &s_cnt, &s_base);
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (nfrag[p] >= 2) a.multi_pixel[m++] = (uint32_t)((size_t)(qy + (p >> 1)) * a.fc.W + (qx + (p & 1)));
     }
-    if (!__syncthreads_or(item ? 1 : 0)) return;
-    const uint32_t k = group_append(a.item_count, item ? 1u : 0u, &s_cnt, &s_base);
-    if (item) {
-        a.item_pixel[k] = (uint32_t)pi;
-        a.item_ray[k] = make_float4(origin.x, origin.y, origin.z, max_depth);
-    }
+    if (!__syncthreads_or(want ? 1 : 0)) return;
+    uint32_t k = group_append(a.item_count, want, &s_cnt, &s_base);
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        if (nfrag[p] == 1 && max_depth[p] > 0.0f) {
+            a.item_pixel[k] = (uint32_t)((size_t)(qy + (p >> 1)) * a.fc.W + (qx + (p & 1)));
+            a.item_ray[k] = make_float4(origin[p].x, origin[p].y, origin[p].z, max_depth[p]);
+            ++k;
+        }
 }
 
 // Fog pass for the pixels k_fog_setup found covered by several fog fragments: every fragment
