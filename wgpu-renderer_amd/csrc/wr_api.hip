@@ -180,6 +180,9 @@ struct WrContext {
     // overflow names its frame.
     uint32_t* d_err = nullptr;
     uint64_t frames_submitted = 0;
+    // The library has queued work of its own on `stream` (counter reset, bin pack / gather, the
+    // static frame's clears) since the last frame forked from it.
+    bool stream_has_work = true;
 
     bool profiling = false, counting = false;
     // Profiling keeps one set of stage-boundary events per frame in a ring; wr_get_stats
@@ -715,9 +718,16 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
     const bool latency_schedule = sched_env ? sched_env[0] == 's' : ctx->nfr == 1;
     hipStream_t ms = f->ms, ss = f->side, fs = latency_schedule ? f->fs : f->side;
     int rc;
-    // order the frame after what the caller has queued on its stream so far
-    WR_HIP(hipEventRecord(f->ev_fork, ctx->stream));
-    WR_HIP(hipStreamWaitEvent(ms, f->ev_fork, 0));
+    // Order the frame after what has been queued on the context's stream so far.  With one frame
+    // in flight, a stream nobody else can queue on (the library's own) and nothing queued there
+    // by the library since the last frame, the only thing on it is the wait for that frame, which
+    // this frame's main stream is behind anyway: the hop to that stream and back (two event
+    // waits, about 25 us of an interactive frame) is left out.
+    if (!(ctx->nfr == 1 && ctx->own_stream && !ctx->stream_has_work && f == &ctx->fr[0])) {
+        WR_HIP(hipEventRecord(f->ev_fork, ctx->stream));
+        WR_HIP(hipStreamWaitEvent(ms, f->ev_fork, 0));
+    }
+    ctx->stream_has_work = false;
     if (prof) WR_HIP(hipEventRecord(ev[0], ms));
     const bool fog_pass = (passes & WR_PASS_FOG) && fm.ntris;
 
@@ -931,6 +941,7 @@ int begin_counted(WrContext* ctx) {
     for (int k = 0; k < ctx->nfr; ++k)
         if (ctx->fr[k].submitted) WR_HIP(hipStreamWaitEvent(ctx->stream, ctx->fr[k].ev_done, 0));
     WR_HIP(hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    ctx->stream_has_work = true;
     return WR_OK;
 }
 
@@ -1197,6 +1208,7 @@ int wr_render_frame_static(WrContext* ctx, const WrCameraUniform* camera, const 
     // The buffer keeps what the last call left: clear what a frame reads before writing it.
     const size_t npx = (size_t)ctx->W * ctx->H;
     WR_HIP(hipMemsetAsync(sf.blend.rp_slot, 0, npx * 4, ctx->stream));
+    ctx->stream_has_work = true;
     if (!(passes & WR_PASS_SHADOWS)) {
         const size_t ns = shadow_buffer_floats(ctx->S);
         hipLaunchKernelGGL(k_fill_f32, dim3((uint32_t)((ns + 255) / 256)), dim3(256), 0, ctx->stream, sf.d_shadow, ns, 1.0f);
@@ -1207,6 +1219,7 @@ int wr_render_frame_static(WrContext* ctx, const WrCameraUniform* camera, const 
     WR_HIP(hipEventRecord(sf.ev_done, sf.ms));
     ctx->fr[0].submitted = true;
     WR_HIP(hipStreamWaitEvent(ctx->stream, sf.ev_done, 0));
+    ctx->stream_has_work = true;  // (the next frame must not touch the shared streams' buffers early)
     return WR_OK;
 }
 
@@ -1291,6 +1304,7 @@ int wr_pack_owned_bins(WrContext* ctx, void* device_dst, uint32_t* out_bins) {
     if (out_bins) *out_bins = (uint32_t)owned;
     FrameRes* f = &ctx->fr[ctx->cur];
     if (f->submitted) WR_HIP(hipStreamWaitEvent(ctx->stream, f->ev_done, 0));
+    ctx->stream_has_work = true;
     if (owned > 0)
         hipLaunchKernelGGL(k_pack_bins, dim3((uint32_t)owned), dim3(256), 0, ctx->stream, f->d_color, (uint32_t*)device_dst,
                            ctx->W, ctx->H, bx, nb, rank, world, 1);
@@ -1305,6 +1319,7 @@ int wr_scatter_bins(WrContext* ctx, const void* device_src, uint32_t rank, uint3
     int owned = (nb - (int)rank + (int)world - 1) / (int)world;
     FrameRes* f = &ctx->fr[ctx->cur];
     if (f->submitted) WR_HIP(hipStreamWaitEvent(ctx->stream, f->ev_done, 0));
+    ctx->stream_has_work = true;
     if (owned > 0)
         hipLaunchKernelGGL(k_pack_bins, dim3((uint32_t)owned), dim3(256), 0, ctx->stream, f->d_color,
                            (uint32_t*)const_cast<void*>(device_src), ctx->W, ctx->H, bx, nb, (int)rank, (int)world, 0);
@@ -1332,6 +1347,7 @@ int wr_gather_bins_via(WrContext* ctx, const WrTransport* tp, uint32_t root) {
     wr_gather_layout((uint32_t)ctx->W, (uint32_t)ctx->H, world, rank, &owned, &slot);
     FrameRes* f = &ctx->fr[ctx->cur];
     if (f->submitted) WR_HIP(hipStreamWaitEvent(ctx->stream, f->ev_done, 0));
+    ctx->stream_has_work = true;
     auto check = [&](int rc, const char* what) { return rc == 0 ? WR_OK : fail(ctx, WR_ERR_DEVICE, std::string("bin gather: ") + what + " failed"); };
     int rc;
     if (rank != root) {
