@@ -852,8 +852,8 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
             else hipLaunchKernelGGL(k_fog_noise_view<false>, vg, dim3(256), 0, fog_st, fa);
             if (prof) WR_HIP(hipEventRecord(ev[9], fog_st));
             WR_HIP(hipStreamWaitEvent(fog_st, f->ev_shadow_done, 0));
-            if (ctx->counting) hipLaunchKernelGGL(k_fog_view_resolve<true>, dim3(item_groups), dim3(256), 0, fog_st, fa);
-            else hipLaunchKernelGGL(k_fog_view_resolve<false>, dim3(item_groups), dim3(256), 0, fog_st, fa);
+            if (ctx->counting) hipLaunchKernelGGL(k_fog_view_resolve<true>, dim3((item_groups + kResolveChunks - 1) / kResolveChunks), dim3(256), 0, fog_st, fa);
+            else hipLaunchKernelGGL(k_fog_view_resolve<false>, dim3((item_groups + kResolveChunks - 1) / kResolveChunks), dim3(256), 0, fog_st, fa);
             if (prof) WR_HIP(hipEventRecord(ev[10], fog_st));
 #ifdef WR_DEV
             for (int l = 0; l < 16; ++l) fa.tables_noise.level[l].dbg_level = 256 + l;
