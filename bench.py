@@ -246,7 +246,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
-    r.set_profiling(True)
+    r.set_profiling(not os.environ.get('BENCH_NO_PROF'))
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)

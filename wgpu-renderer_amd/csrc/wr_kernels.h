@@ -1179,7 +1179,11 @@ constexpr int kFogSetupThreads = 256;  // a thread takes a 2x2 pixel quad
 template <bool COUNT>
 __global__ __launch_bounds__(kFogSetupThreads) void k_fog_setup(FogArgs a) {
     latency_bound_kernel();
-    __shared__ StagedRec srec[256];
+    // Records are staged 64 at a time (5.6 KB): a fog volume has a dozen triangles, and a workgroup
+    // that asks for little LDS finds a place on a compute unit whose LDS the shadow rasteriser's
+    // tiles have all but filled.
+    constexpr uint32_t kStage = 64;
+    __shared__ StagedRec srec[kStage];
     __shared__ uint32_t s_m, s_cnt, s_base;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int bx0 = blockIdx.x * kFogBlock, by0 = blockIdx.y * kFogBlock;
@@ -1209,10 +1213,10 @@ __global__ __launch_bounds__(kFogSetupThreads) void k_fog_setup(FogArgs a) {
         hit_E[p][0] = hit_E[p][1] = hit_E[p][2] = 0;
     }
     const uint32_t nrec = a.ws.slots + min(a.ws.ovf_count[0], a.ws.ovf_cap);
-    for (uint32_t c0 = 0; c0 < nrec; c0 += 256) {
+    for (uint32_t c0 = 0; c0 < nrec; c0 += kStage) {
         if (tid == 0) s_m = 0;
         __syncthreads();
-        if (c0 + tid < nrec) {
+        if ((uint32_t)tid < kStage && c0 + tid < nrec) {
             const Rec* rp = &a.ws.recs[c0 + tid];
             const uint2 bb = a.ws.bb[c0 + tid];
             const uint32_t bbmin = bb.x, bbmax = bb.y;
