@@ -323,6 +323,9 @@ int wr_comm_unique_id(uint8_t id[128]);
 int wr_comm_create(const uint8_t id[128], uint32_t rank, uint32_t world, int32_t device, void** out_comm);
 int wr_comm_destroy(void* comm);
 
+/* enabled: 0 off; 1 records HIP events around every stage (a dozen per frame: a few per cent of a
+ * frame that has the device to itself); 2 only those around the fog noise / march kernels, which
+ * fills ms_fog_march and ms_fog_light_march and leaves the other times at zero. */
 int wr_set_profiling(WrContext* ctx, int enabled);
 /* enabled != 0 makes the next frames also count fragments / march steps with atomics
  * (slower, and a counted call does not overlap the frames before it; never enable it inside

@@ -462,6 +462,37 @@ def test_resize_and_scene_reuse(tiny_scene):
     r.close()
 
 
+@pytest.mark.parametrize("in_flight", [1, 2])
+def test_profiling_levels(small_scene, in_flight):
+    """Level 1 times every stage, level 2 only the fog noise / march kernels (what a timed run can
+    afford); neither changes a pixel."""
+    w, h, s = 400, 225, 256
+    cam, light, glob = default_inputs(w, h)
+    plain = render_gpu(small_scene, cam, light, glob, abi.PASS_ALL, w, h, s)["color"]
+    r = abi.Renderer(w, h, s, frames_in_flight=in_flight)
+    r.upload_scene(small_scene)
+    r.set_profiling(1)
+    for _ in range(5):
+        r.render_frame(cam, light, glob, abi.PASS_ALL)
+    st = r.stats()
+    assert st.profiled_frames == 5
+    assert min(st.ms_shadow, st.ms_geometry, st.ms_shade, st.ms_fog, st.ms_fog_march) > 0.0
+    assert st.ms_total >= max(st.ms_shadow, st.ms_geometry, st.ms_fog_march)
+    if in_flight == 1:  # the split march has a light-noise kernel of its own
+        assert st.ms_fog_light_march > 0.2 * st.ms_fog_march
+    else:
+        assert st.ms_fog_light_march < 0.2 * st.ms_fog_march
+    r.set_profiling(2)
+    for _ in range(3):
+        r.render_frame(cam, light, glob, abi.PASS_ALL)
+    st = r.stats()
+    assert st.profiled_frames == 3 and st.ms_fog_march > 0.0
+    assert st.ms_shadow == st.ms_geometry == st.ms_shade == st.ms_fog == st.ms_total == 0.0
+    assert np.array_equal(r.read_color(), plain)
+    r.set_profiling(0)
+    r.close()
+
+
 def test_list_overflow_is_reported_with_its_frame(tiny_scene, monkeypatch):
     """A frame whose bin item list overflows is reported at the next wr_sync, by its number in
     submission order (each set of frame buffers has its own error word), and the context goes

@@ -184,7 +184,9 @@ struct WrContext {
     // static frame's clears) since the last frame forked from it.
     bool stream_has_work = true;
 
-    bool profiling = false, counting = false;
+    int ev_level = 0;   // level the recorded frames' events were taken at
+    int profiling = 0;  // 0 off, 1 every stage's events, 2 only the events around the fog noise / march kernels
+    bool counting = false;
     // Profiling keeps one set of stage-boundary events per frame in a ring; wr_get_stats
     // averages the stage times over the frames recorded since profiling was switched on.
     static constexpr int kEvFrames = 128;
@@ -712,7 +714,8 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
     const ModelDev& g = ctx->dev[WR_MODEL_GEOMETRY];
     const ModelDev& lm = ctx->dev[WR_MODEL_LIGHT_MARKER];
     const ModelDev& fm = ctx->dev[WR_MODEL_FOG_VOLUME];
-    const bool prof = ctx->profiling;
+    const bool prof = ctx->profiling == 1;        // all stage events
+    const bool prof_march = ctx->profiling != 0;  // the events around the dominant kernels
     hipEvent_t* ev = ctx->ev[ctx->ev_next];
     static const char* sched_env = getenv("WR_DEBUG_SCHEDULE");  // "split" / "mono": force a fog schedule
     const bool latency_schedule = sched_env ? sched_env[0] == 's' : ctx->nfr == 1;
@@ -845,16 +848,16 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
         dim3 fg((uint32_t)(ctx->W + kFogBlock - 1) / kFogBlock, (uint32_t)(ctx->H + kFogBlock - 1) / kFogBlock, 1);
         if (ctx->counting) hipLaunchKernelGGL(k_fog_setup<true>, fg, dim3(kFogSetupThreads), 0, fog_st, fa);
         else hipLaunchKernelGGL(k_fog_setup<false>, fg, dim3(kFogSetupThreads), 0, fog_st, fa);
-        if (prof) WR_HIP(hipEventRecord(ev[6], fog_st));
+        if (prof_march) WR_HIP(hipEventRecord(ev[6], fog_st));
         if (latency_schedule) {
             const dim3 vg(item_groups * (uint32_t)kFogViewGroups, 1, 1);
             if (ctx->counting) hipLaunchKernelGGL(k_fog_noise_view<true>, vg, dim3(256), 0, fog_st, fa);
             else hipLaunchKernelGGL(k_fog_noise_view<false>, vg, dim3(256), 0, fog_st, fa);
-            if (prof) WR_HIP(hipEventRecord(ev[9], fog_st));
+            if (prof_march) WR_HIP(hipEventRecord(ev[9], fog_st));
             WR_HIP(hipStreamWaitEvent(fog_st, f->ev_shadow_done, 0));
             if (ctx->counting) hipLaunchKernelGGL(k_fog_view_resolve<true>, dim3((item_groups + kResolveChunks - 1) / kResolveChunks), dim3(256), 0, fog_st, fa);
             else hipLaunchKernelGGL(k_fog_view_resolve<false>, dim3((item_groups + kResolveChunks - 1) / kResolveChunks), dim3(256), 0, fog_st, fa);
-            if (prof) WR_HIP(hipEventRecord(ev[10], fog_st));
+            if (prof_march) WR_HIP(hipEventRecord(ev[10], fog_st));
 #ifdef WR_DEV
             for (int l = 0; l < 16; ++l) fa.tables_noise.level[l].dbg_level = 256 + l;
 #endif
@@ -866,14 +869,14 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
             const dim3 mg((uint32_t)((npx + 63) / 64), 1, 1);
             if (ctx->counting) hipLaunchKernelGGL(k_fog_march<true>, mg, dim3(64), 0, fog_st, fa);
             else hipLaunchKernelGGL(k_fog_march<false>, mg, dim3(64), 0, fog_st, fa);
-            if (prof) { WR_HIP(hipEventRecord(ev[9], fog_st)); WR_HIP(hipEventRecord(ev[10], fog_st)); }
+            if (prof_march) { WR_HIP(hipEventRecord(ev[9], fog_st)); WR_HIP(hipEventRecord(ev[10], fog_st)); }
         }
-    } else if (prof) {
+    } else if (prof_march) {
         WR_HIP(hipEventRecord(ev[6], fog_st));
         WR_HIP(hipEventRecord(ev[9], fog_st));
         WR_HIP(hipEventRecord(ev[10], fog_st));
     }
-    if (prof) WR_HIP(hipEventRecord(ev[5], fog_st));
+    if (prof_march) WR_HIP(hipEventRecord(ev[5], fog_st));
     if (!swap_roles) WR_HIP(hipEventRecord(f->ev_join, fog_st));  // what the main stream waits for before the fog blend:
 
     // shading (reads the shadow maps; on another stream than the geometry pass it also waits for that)
@@ -915,8 +918,8 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
     }
     if (ctx->cfg.color_format == WR_FORMAT_BGRA8_UNORM_SRGB)
         hipLaunchKernelGGL(k_swap_red_blue, dim3(1024), dim3(256), 0, ms, f->d_color, npx);
-    if (prof) {
-        WR_HIP(hipEventRecord(ev[7], ms));
+    if (prof) WR_HIP(hipEventRecord(ev[7], ms));
+    if (prof_march) {
         ctx->ev_next = (ctx->ev_next + 1) % WrContext::kEvFrames;
         if (ctx->ev_count < WrContext::kEvFrames) ++ctx->ev_count;
     }
@@ -1451,7 +1454,8 @@ int wr_comm_destroy(void* comm) {
 
 int wr_set_profiling(WrContext* ctx, int enabled) {
     if (!ctx) return WR_ERR_INVALID_ARGUMENT;
-    ctx->profiling = enabled != 0;
+    ctx->profiling = enabled == 2 ? 2 : (enabled != 0 ? 1 : 0);
+    ctx->ev_level = ctx->profiling;
     ctx->ev_count = 0;
     ctx->ev_next = 0;
     return WR_OK;
@@ -1472,12 +1476,12 @@ int wr_get_stats(WrContext* ctx, WrFrameStats* out) {
         const int a[7] = {1, 0, 3, 8, 0, 6, 10}, b[7] = {2, 3, 4, 5, 7, 9, 5};  // shadow, geometry, shade, fog, frame, view noise, light noise
         double ms[7] = {0, 0, 0, 0, 0, 0, 0};
         for (int k = 0; k < ctx->ev_count; ++k)
-            for (int i = 0; i < 7; ++i) {
+            for (int i = (ctx->ev_level == 2 ? 5 : 0); i < 7; ++i) {  // (level 2 recorded the last two pairs only)
                 float t = 0.0f;
                 WR_HIP(hipEventElapsedTime(&t, ctx->ev[k][a[i]], ctx->ev[k][b[i]]));
                 ms[i] += t;
             }
-        for (int i = 0; i < 7; ++i) ms[i] /= ctx->ev_count;
+        for (int i = 0; i < 7; ++i) ms[i] /= ctx->ev_count;  // (zero where nothing was recorded)
         ctx->stats.ms_shadow = (float)ms[0]; ctx->stats.ms_geometry = (float)ms[1];
         ctx->stats.ms_shade = (float)ms[2]; ctx->stats.ms_fog = (float)ms[3];
         ctx->stats.ms_total = (float)ms[4];
