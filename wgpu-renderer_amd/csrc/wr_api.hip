@@ -40,6 +40,10 @@ static_assert(sizeof(WrMaterialUniform) == 16, "MaterialUniform layout (material
 #define WR_COLOR_RASTER_THREADS 256
 #endif
 constexpr int kColorRasterThreads = WR_COLOR_RASTER_THREADS;
+// With one frame in flight the geometry raster is on the frame's critical path and its longest
+// bins (dozens of bin-filling triangles, one per wavefront at a time) set its length: eight
+// wavefronts per bin instead of four.  With frames overlapping the smaller workgroup is better.
+constexpr int kColorRasterThreadsAlone = 512;
 #ifndef WR_SHADOW_RASTER_THREADS
 #define WR_SHADOW_RASTER_THREADS 256
 #endif
@@ -552,6 +556,9 @@ int bin_and_raster(WrContext* ctx, FrameRes* f, hipStream_t st, WsAlloc& w, bool
     if (shadow)
         hipLaunchKernelGGL((k_raster<kRasterShadow, kShadowRasterThreads>), g, dim3(kShadowRasterThreads), 0, st, ws, ctx->S, ctx->S, (uint32_t*)nullptr,
                            f->d_shadow, 0, 1, LayerSink{});
+    else if (ctx->nfr == 1)
+        hipLaunchKernelGGL((k_raster<kRasterColor, kColorRasterThreadsAlone>), g, dim3(kColorRasterThreadsAlone), 0, st, ws, ctx->W, ctx->H, f->d_vis,
+                           f->d_depth, tr, tw, LayerSink{});
     else
         hipLaunchKernelGGL((k_raster<kRasterColor, kColorRasterThreads>), g, dim3(kColorRasterThreads), 0, st, ws, ctx->W, ctx->H, f->d_vis,
                            f->d_depth, tr, tw, LayerSink{});
