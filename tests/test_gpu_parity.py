@@ -302,6 +302,49 @@ def test_frames_in_flight_match_one(small_scene, in_flight):
     two.close()
 
 
+@pytest.mark.parametrize("size", ["small", "full"])
+def test_back_to_back_frames_on_one_set_of_buffers(small_scene, full_scene, size):
+    """One frame in flight, frames submitted back to back without a host synchronisation: the
+    library lets the next frame's vertex and triangle set-up run next to the previous frame's fog
+    tail (its two streams exchange roles with every frame).  Every frame must still be the frame
+    rendered alone: camera, light and time change from frame to frame, and so do the passes."""
+    import torch
+    sc, (w, h, s) = (small_scene, (400, 225, 256)) if size == "small" else (full_scene, (1920, 1080, 2048))
+    ks = (0, 9, 21, 40, 63, 33, 50)
+    cams = [default_inputs(w, h, pose=scene.flythrough_pose(k, 64))[0] for k in ks]
+    lights = [abi.light_at_time(1.0 + 0.7 * k) for k in range(len(cams))]
+    globs = [abi.global_uniforms(1.0 + 0.7 * k, 1) for k in range(len(cams))]
+    passes = [abi.PASS_ALL, abi.PASS_ALL, abi.PASS_SHADOWS | abi.PASS_LIGHT_DEBUG, abi.PASS_ALL, abi.PASS_FOG, abi.PASS_ALL, abi.PASS_ALL]
+    one = abi.Renderer(w, h, s)
+    one.upload_scene(sc)
+    ref = []
+    for c, l, g, p in zip(cams, lights, globs, passes):
+        one.render_frame(c, l, g, p)
+        one.sync()
+        ref.append((one.read_color(), one.read_depth(), one.read_shadow_map()))
+    assert len({r[0].tobytes() for r in ref}) == len(ref)  # (the frames differ)
+    r = abi.Renderer(w, h, s, frames_in_flight=1)
+    r.upload_scene(sc)
+    for n in (2, 3, 4, 5, 7):  # n frames back to back, then the last one is looked at: both stream roles end a run
+        for c, l, g, p in list(zip(cams, lights, globs, passes))[:n]:
+            r.render_frame(c, l, g, p)
+        assert np.array_equal(r.read_color(), ref[n - 1][0]), n
+        assert np.array_equal(r.read_depth(), ref[n - 1][1]), n
+        assert np.array_equal(r.read_shadow_map(), ref[n - 1][2]), n
+    # every frame of a batch, copied to device memory behind its frame
+    frames = torch.zeros((len(cams), h, w, 4), dtype=torch.uint8, device="cuda")
+    for rep in range(2):
+        r.render_batch(cams, lights[0], globs[0], abi.PASS_ALL, shadows_every_frame=True, device_frames=frames.data_ptr())
+    r.sync()
+    torch.cuda.synchronize()
+    got = frames.cpu().numpy()
+    for k, c in enumerate(cams):
+        one.render_frame(c, lights[0], globs[0], abi.PASS_ALL)
+        assert np.array_equal(one.read_color(), got[k]), k
+    one.close()
+    r.close()
+
+
 @pytest.mark.parametrize("in_flight", [1, 3])
 def test_state_shared_between_frames_in_flight(small_scene, in_flight):
     """What frames share across the sets of frame buffers: a frame without shadow passes sees

@@ -127,6 +127,9 @@ struct FrameRes {
     hipStream_t ms = nullptr, side = nullptr, fs = nullptr;
     hipEvent_t ev_fork = nullptr, ev_start = nullptr, ev_join = nullptr, ev_shadow_done = nullptr, ev_geom_done = nullptr, ev_done = nullptr;
     hipEvent_t ev_prologue_done = nullptr;  // fog volume set-up and noise tables done (one frame in flight)
+    hipEvent_t ev_fog_volume_done = nullptr;  // fog volume set-up done (one frame in flight)
+    hipEvent_t ev_targets_free = nullptr;     // the frame has read its depth and shadow maps for the last time (one frame in flight)
+    hipStream_t cur_ms = nullptr;           // the stream the frame in these buffers ends on (see frame_stages)
     bool submitted = false;  // ev_done has been recorded
     uint64_t serial = 0;     // number (from 1) of the last frame submitted to this set
     // d_shadow holds the cleared depth (1.0 everywhere), the value a frame without shadow passes
@@ -187,6 +190,7 @@ struct WrContext {
     // The library has queued work of its own on `stream` (counter reset, bin pack / gather, the
     // static frame's clears) since the last frame forked from it.
     bool stream_has_work = true;
+    bool flip_streams = false;  // one frame in flight: the main and the fog stream change roles with every frame
 
     int ev_level = 0;   // level the recorded frames' events were taken at
     int profiling = 0;  // 0 off, 1 every stage's events, 2 only the events around the fog noise / march kernels
@@ -547,12 +551,14 @@ FrameConsts make_consts(const WrContext* ctx, const WrCameraUniform* cam, const 
 
 dim3 grid1(uint32_t n, uint32_t layers = 1) { return dim3((n + 255u) / 256u, layers, 1); }
 
-int bin_and_raster(WrContext* ctx, FrameRes* f, hipStream_t st, WsAlloc& w, bool shadow, int tr, int tw) {
+int bin_and_raster(WrContext* ctx, FrameRes* f, hipStream_t st, WsAlloc& w, bool shadow, int tr, int tw,
+                   hipEvent_t prev_done = nullptr) {
     RasterWS& ws = w.ws;
     uint32_t nrec = ws.slots + ws.ovf_cap;
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(kScanThreads), 0, st, ws);
     hipLaunchKernelGGL(k_bin_fill, grid1(nrec, ws.layers), dim3(256), 0, st, ws, tr, tw);
     dim3 g((uint32_t)(ws.bins_x * ws.bins_y), (uint32_t)ws.layers, 1);
+    if (prev_done) WR_HIP(hipStreamWaitEvent(st, prev_done, 0));  // the previous frame's fog tail reads the target this raster writes
     if (shadow)
         hipLaunchKernelGGL((k_raster<kRasterShadow, kShadowRasterThreads>), g, dim3(kShadowRasterThreads), 0, st, ws, ctx->S, ctx->S, (uint32_t*)nullptr,
                            f->d_shadow, 0, 1, LayerSink{});
@@ -565,14 +571,14 @@ int bin_and_raster(WrContext* ctx, FrameRes* f, hipStream_t st, WsAlloc& w, bool
     return WR_OK;
 }
 
-int shadow_stage(WrContext* ctx, FrameRes* f, hipStream_t st, const FrameConsts& fc) {
+int shadow_stage(WrContext* ctx, FrameRes* f, hipStream_t st, const FrameConsts& fc, hipEvent_t prev_done = nullptr) {
     const ModelDev& g = ctx->dev[WR_MODEL_GEOMETRY];
     hipLaunchKernelGGL(k_vs_shadow, grid1(g.nv, 6), dim3(256), 0, st, g.pos, g.nv, f->d_shadow_clip, fc);
     hipLaunchKernelGGL(k_setup<true>, grid1(g.ntris, 6), dim3(256), 0, st, f->d_shadow_clip, g.nv, g.idx, g.ntris,
                        f->shadow.ws, ctx->S, ctx->S, 0, 1);
     hipLaunchKernelGGL(k_setup_clip<true>, dim3(128, 6, 1), dim3(64), 0, st, f->d_shadow_clip, g.nv, g.idx, f->shadow.ws,
                        ctx->S, ctx->S, 0, 1);
-    return bin_and_raster(ctx, f, st, f->shadow, true, 0, 1);
+    return bin_and_raster(ctx, f, st, f->shadow, true, 0, 1, prev_done);
 }
 
 // World-space box around the points the fog marches of this frame can sample: the part of the
@@ -727,13 +733,29 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
     static const char* sched_env = getenv("WR_DEBUG_SCHEDULE");  // "split" / "mono": force a fog schedule
     const bool latency_schedule = sched_env ? sched_env[0] == 's' : ctx->nfr == 1;
     hipStream_t ms = f->ms, ss = f->side, fs = latency_schedule ? f->fs : f->side;
+    // One frame in flight: a frame ends with the fog pass's tail (light march, fog blend) on its
+    // main stream, while its other stream is idle since the shading kernels ended 0.1 ms earlier;
+    // the next frame begins with 0.13 ms of vertex and triangle set-up that leave most of the
+    // device idle and touch nothing the fog tail reads.  So the two streams exchange roles with
+    // every frame: the next frame's geometry set-up queues behind the previous frame's shading
+    // (whose inputs it overwrites) and runs next to its fog tail; what does touch the tail's data
+    // is behind it on the tail's stream (fog volume, noise tables, later the shading kernels) or
+    // waits for the previous frame's end (the two rasterisers: depth and shadow maps).
+    const bool flipping = latency_schedule && f->fs != f->ms && f->fs != f->side && f->side != f->ms;
+    if (flipping) {
+        if (ctx->flip_streams) std::swap(ms, fs);
+        ctx->flip_streams = !ctx->flip_streams;
+    }
+    f->cur_ms = ms;
+    const hipEvent_t prev_done = flipping ? f->ev_targets_free : nullptr;
     int rc;
     // Order the frame after what has been queued on the context's stream so far.  With one frame
     // in flight, a stream nobody else can queue on (the library's own) and nothing queued there
     // by the library since the last frame, the only thing on it is the wait for that frame, which
     // this frame's main stream is behind anyway: the hop to that stream and back (two event
     // waits, about 25 us of an interactive frame) is left out.
-    if (!(ctx->nfr == 1 && ctx->own_stream && !ctx->stream_has_work && f == &ctx->fr[0])) {
+    const bool follows_own_frame = ctx->nfr == 1 && ctx->own_stream && !ctx->stream_has_work && f == &ctx->fr[0];
+    if (!follows_own_frame) {
         WR_HIP(hipEventRecord(f->ev_fork, ctx->stream));
         WR_HIP(hipStreamWaitEvent(ms, f->ev_fork, 0));
     }
@@ -748,18 +770,39 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
         cl.ptr[0] = f->geom.counters; cl.words[0] = (uint32_t)(f->geom.counters_bytes / 4);
         cl.ptr[1] = f->blend.counts; cl.words[1] = (uint32_t)(f->blend_clear_bytes / 4);
         cl.ptr[2] = f->shadow.counters; cl.words[2] = (uint32_t)(f->shadow.counters_bytes / 4);
-        cl.ptr[3] = f->fog.counters; cl.words[3] = (uint32_t)(f->fog.counters_bytes / 4);
+        if (!flipping) { cl.ptr[3] = f->fog.counters; cl.words[3] = (uint32_t)(f->fog.counters_bytes / 4); }
         hipLaunchKernelGGL(k_clear_words, dim3(32), dim3(256), 0, ms, cl);
     }
     // after this set's previous frame and the caller's earlier work
     WR_HIP(hipEventRecord(f->ev_start, ms));
     WR_HIP(hipStreamWaitEvent(ss, f->ev_start, 0));
     if (fs != ss) WR_HIP(hipStreamWaitEvent(fs, f->ev_start, 0));
-
-    // Submission takes the host about as long as the device needs for half a frame, so the
-    // order of the two independent chains matters: the one the frame's critical path starts
-    // with goes first (one frame in flight: geometry, which the view march waits for; frames
-    // overlapping: the shadow passes, the longer chain, which shading waits for).
+    if (flipping) {
+        // (the previous frame's fog tail reads the fog pass's counters: cleared behind it)
+        ClearList cg{};
+        cg.ptr[0] = f->fog.counters; cg.words[0] = (uint32_t)(f->fog.counters_bytes / 4);
+        hipLaunchKernelGGL(k_clear_words, dim3(8), dim3(256), 0, fs, cg);
+    }
+    FogArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    auto fill_fog_args = [&]() {
+        fa.fc = fc; fa.ws = f->fog.ws; fa.pos = fm.pos; fa.idx = fm.idx; fa.ntris = fm.ntris;
+        fa.depth = f->d_depth; fa.color = f->d_color; fa.shadow = f->d_shadow; fa.tables = ctx->d_tables;
+        fa.counters = ctx->d_counters;
+        // the fog workspace has one bin and is not binned, so its bin_count and bin_cursor words
+        // are free: they count the march items and the pixels with several fog fragments; the
+        // word after its clip_count counts the lit fog points
+        fa.item_count = f->fog.ws.bin_count; fa.item_pixel = f->d_fog_pixel; fa.item_ray = f->d_fog_ray;
+        fa.multi_count = f->fog.ws.bin_cursor; fa.multi_pixel = f->d_fog_multi;
+        fa.lit_count = f->fog.ws.clip_count + 1; fa.lit_item = f->d_fog_lit;
+        fa.item_res = f->d_fog_res; fa.noise_view = f->d_fog_noise_view; fa.noise_light = f->d_fog_noise_light;
+        fa.cap = (uint32_t)((size_t)ctx->W * ctx->H);
+    };
+    if (fog_pass) fill_fog_args();
+    const dim3 fog_grid((uint32_t)(ctx->W + kFogBlock - 1) / kFogBlock, (uint32_t)(ctx->H + kFogBlock - 1) / kFogBlock, 1);
+    auto submit_fog_volume = [&]() {
+        hipLaunchKernelGGL(k_setup_small, dim3((fm.ntris + kSmallTris - 1) / kSmallTris), dim3(64), 0, fs, fm.pos, fm.idx, fm.ntris, 1, 1, 0u, f->fog.ws, fc);
+    };
     auto submit_geometry = [&]() -> int {
         // main stream: geometry + light marker -> visibility / depth
         VertexIn vin{g.pos, g.uv, g.nrm, g.tan, g.bit, g.nv};
@@ -769,9 +812,9 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
         hipLaunchKernelGGL(k_setup_clip<false>, dim3(256, 1, 1), dim3(64), 0, ms, f->vout.clip, g.nv, g.idx, f->geom.ws,
                            ctx->W, ctx->H, fc.geom_tile_rank, fc.geom_tile_world);
         if (lm.ntris)
-            hipLaunchKernelGGL(k_setup_small, grid1(lm.ntris), dim3(256), 0, ms, lm.pos, lm.idx, lm.ntris, 0,
+            hipLaunchKernelGGL(k_setup_small, dim3((lm.ntris + kSmallTris - 1) / kSmallTris), dim3(64), 0, ms, lm.pos, lm.idx, lm.ntris, 0,
                                (passes & WR_PASS_LIGHT_DEBUG) ? 1 : 0, g.ntris, f->geom.ws, fc);
-        if ((rc = bin_and_raster(ctx, f, ms, f->geom, false, fc.geom_tile_rank, fc.geom_tile_world)) != WR_OK) return rc;
+        if ((rc = bin_and_raster(ctx, f, ms, f->geom, false, fc.geom_tile_rank, fc.geom_tile_world, prev_done)) != WR_OK) return rc;
         if (prof) WR_HIP(hipEventRecord(ev[3], ms));
         WR_HIP(hipEventRecord(f->ev_geom_done, ms));
         return WR_OK;
@@ -780,13 +823,14 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
         // side stream: shadow maps
         if (prof) WR_HIP(hipEventRecord(ev[1], ss));
         if (do_shadow && (passes & WR_PASS_SHADOWS)) {
-            if ((rc = shadow_stage(ctx, f, ss, fc)) != WR_OK) return rc;
+            if ((rc = shadow_stage(ctx, f, ss, fc, prev_done)) != WR_OK) return rc;
             f->shadow_is_clear = false;
         } else if (do_shadow && !f->shadow_is_clear) {
             // No shadow passes in this frame: it sees cleared maps, whatever frame used this set
             // of buffers before (the reference clears each face to 1.0 before drawing into it,
             // state.rs:655-657; a frame that draws nothing leaves that).
             const size_t ns = shadow_buffer_floats(ctx->S);
+            if (prev_done) WR_HIP(hipStreamWaitEvent(ss, prev_done, 0));
             hipLaunchKernelGGL(k_fill_f32, dim3((uint32_t)((ns + 255) / 256)), dim3(256), 0, ss, f->d_shadow, ns, 1.0f);
             f->shadow_is_clear = true;
         }
@@ -795,11 +839,10 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
         return WR_OK;
     };
     // fog volume set-up and noise tables: they need the frame constants only
-    FogArgs fa;
-    memset(&fa, 0, sizeof(fa));
-    auto submit_fog_prologue = [&]() {
+    auto submit_fog_prologue = [&]() -> int {
         if (fog_pass) {
-            hipLaunchKernelGGL(k_setup_small, grid1(fm.ntris), dim3(256), 0, fs, fm.pos, fm.idx, fm.ntris, 1, 1, 0u, f->fog.ws, fc);
+            submit_fog_volume();
+            if (fs != ms) WR_HIP(hipEventRecord(f->ev_fog_volume_done, fs));
             uint32_t max_entries = 0;
             fa.tables_noise = plan_noise_tables(ctx, f, fc, &max_entries);
             if (max_entries) {
@@ -813,15 +856,16 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
                 hipLaunchKernelGGL(k_fog_tables, dim3(plan.wg_begin[16]), dim3(256), 0, fs, fa.tables_noise, plan);
             }
         }
+        return WR_OK;
     };
     if (latency_schedule) {
         if ((rc = submit_geometry()) != WR_OK) return rc;
-        submit_fog_prologue();
+        if ((rc = submit_fog_prologue()) != WR_OK) return rc;
         if ((rc = submit_shadows()) != WR_OK) return rc;
     } else {
         if ((rc = submit_shadows()) != WR_OK) return rc;
         if ((rc = submit_geometry()) != WR_OK) return rc;
-        submit_fog_prologue();
+        if ((rc = submit_fog_prologue()) != WR_OK) return rc;
     }
     // One frame in flight: the frame's critical path is geometry -> fog set-up -> marches -> fog
     // blend, so those stay on ONE stream (the main one; a wait across streams costs 10-25 us each
@@ -832,7 +876,7 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
     hipStream_t fog_st = swap_roles ? ms : fs, shade_st = swap_roles ? fs : ms;
     if (swap_roles) {
         WR_HIP(hipEventRecord(f->ev_prologue_done, fs));
-        WR_HIP(hipStreamWaitEvent(ms, f->ev_prologue_done, 0));
+        if (fog_pass) WR_HIP(hipStreamWaitEvent(ms, f->ev_fog_volume_done, 0));
         WR_HIP(hipStreamWaitEvent(fs, f->ev_geom_done, 0));
     } else {
         WR_HIP(hipStreamWaitEvent(fs, f->ev_geom_done, 0));
@@ -841,20 +885,9 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
     const size_t npx = (size_t)ctx->W * ctx->H;
     const uint32_t item_groups = (uint32_t)((npx + 255) / 256);
     if (fog_pass) {
-        fa.fc = fc; fa.ws = f->fog.ws; fa.pos = fm.pos; fa.idx = fm.idx; fa.ntris = fm.ntris;
-        fa.depth = f->d_depth; fa.color = f->d_color; fa.shadow = f->d_shadow; fa.tables = ctx->d_tables;
-        fa.counters = ctx->d_counters;
-        // the fog workspace has one bin and is not binned, so its bin_count and bin_cursor words
-        // are free: they count the march items and the pixels with several fog fragments; the
-        // word after its clip_count counts the lit fog points
-        fa.item_count = f->fog.ws.bin_count; fa.item_pixel = f->d_fog_pixel; fa.item_ray = f->d_fog_ray;
-        fa.multi_count = f->fog.ws.bin_cursor; fa.multi_pixel = f->d_fog_multi;
-        fa.lit_count = f->fog.ws.clip_count + 1; fa.lit_item = f->d_fog_lit;
-        fa.item_res = f->d_fog_res; fa.noise_view = f->d_fog_noise_view; fa.noise_light = f->d_fog_noise_light;
-        fa.cap = (uint32_t)npx;
-        dim3 fg((uint32_t)(ctx->W + kFogBlock - 1) / kFogBlock, (uint32_t)(ctx->H + kFogBlock - 1) / kFogBlock, 1);
-        if (ctx->counting) hipLaunchKernelGGL(k_fog_setup<true>, fg, dim3(kFogSetupThreads), 0, fog_st, fa);
-        else hipLaunchKernelGGL(k_fog_setup<false>, fg, dim3(kFogSetupThreads), 0, fog_st, fa);
+        if (ctx->counting) hipLaunchKernelGGL(k_fog_setup<true>, fog_grid, dim3(kFogSetupThreads), 0, fog_st, fa);
+        else hipLaunchKernelGGL(k_fog_setup<false>, fog_grid, dim3(kFogSetupThreads), 0, fog_st, fa);
+        if (swap_roles) WR_HIP(hipStreamWaitEvent(ms, f->ev_prologue_done, 0));  // the noise tables
         if (prof_march) WR_HIP(hipEventRecord(ev[6], fog_st));
         if (latency_schedule) {
             const dim3 vg(item_groups * (uint32_t)kFogViewGroups, 1, 1);
@@ -917,11 +950,23 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
     // main stream: fog colours over the finished geometry colour
     WR_HIP(hipStreamWaitEvent(ms, f->ev_join, 0));
     if (fog_pass) {
-        if (!latency_schedule) hipLaunchKernelGGL(k_fog_blend, dim3(2048), dim3(256), 0, ms, fa);
-        else if (ctx->counting) hipLaunchKernelGGL(k_fog_shade_blend<true>, dim3(2048), dim3(256), 0, ms, fa);
-        else hipLaunchKernelGGL(k_fog_shade_blend<false>, dim3(2048), dim3(256), 0, ms, fa);
-        if (ctx->counting) hipLaunchKernelGGL(k_fog_multi<true>, dim3(1024), dim3(64), 0, ms, fa);
-        else hipLaunchKernelGGL(k_fog_multi<false>, dim3(1024), dim3(64), 0, ms, fa);
+        // (the two kernels write different pixels: a pixel with one fog fragment is a march item,
+        // one with several is on k_fog_multi's list.  k_fog_multi is the last reader of the depth,
+        // the shadow maps and the fog volume's records: the next frame's rasterisers wait for it,
+        // not for the frame's end.)
+        if (latency_schedule) {
+            if (ctx->counting) hipLaunchKernelGGL(k_fog_multi<true>, dim3(1024), dim3(64), 0, ms, fa);
+            else hipLaunchKernelGGL(k_fog_multi<false>, dim3(1024), dim3(64), 0, ms, fa);
+            WR_HIP(hipEventRecord(f->ev_targets_free, ms));
+            if (ctx->counting) hipLaunchKernelGGL(k_fog_shade_blend<true>, dim3(2048), dim3(256), 0, ms, fa);
+            else hipLaunchKernelGGL(k_fog_shade_blend<false>, dim3(2048), dim3(256), 0, ms, fa);
+        } else {
+            hipLaunchKernelGGL(k_fog_blend, dim3(2048), dim3(256), 0, ms, fa);
+            if (ctx->counting) hipLaunchKernelGGL(k_fog_multi<true>, dim3(1024), dim3(64), 0, ms, fa);
+            else hipLaunchKernelGGL(k_fog_multi<false>, dim3(1024), dim3(64), 0, ms, fa);
+        }
+    } else if (latency_schedule) {
+        WR_HIP(hipEventRecord(f->ev_targets_free, ms));
     }
     if (ctx->cfg.color_format == WR_FORMAT_BGRA8_UNORM_SRGB)
         hipLaunchKernelGGL(k_swap_red_blue, dim3(1024), dim3(256), 0, ms, f->d_color, npx);
@@ -937,7 +982,7 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
 // Marks the end of a frame's work on its main stream.  With one frame in flight the caller's
 // stream continues after the frame, as if the frame had run there.
 int finish_frame(WrContext* ctx, FrameRes* f) {
-    WR_HIP(hipEventRecord(f->ev_done, f->ms));
+    WR_HIP(hipEventRecord(f->ev_done, f->cur_ms));
     f->submitted = true;
     f->serial = ++ctx->frames_submitted;
     if (ctx->nfr == 1) WR_HIP(hipStreamWaitEvent(ctx->stream, f->ev_done, 0));
@@ -1028,7 +1073,7 @@ int wr_create(const WrConfig* config, WrContext** out_ctx) {
                 WR_HIP(hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
                 WR_HIP(hipStreamCreateWithFlags(&f->fs, hipStreamNonBlocking));
             }
-            hipEvent_t* evs[] = {&f->ev_fork, &f->ev_start, &f->ev_join, &f->ev_shadow_done, &f->ev_geom_done, &f->ev_done, &f->ev_prologue_done};
+            hipEvent_t* evs[] = {&f->ev_fork, &f->ev_start, &f->ev_join, &f->ev_shadow_done, &f->ev_geom_done, &f->ev_done, &f->ev_prologue_done, &f->ev_fog_volume_done, &f->ev_targets_free};
             for (hipEvent_t* e : evs) WR_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         }
         float tables[768];
@@ -1075,7 +1120,7 @@ void wr_destroy(WrContext* ctx) {
         if (f.ms) (void)hipStreamDestroy(f.ms);
         if (f.side && f.side != f.ms) (void)hipStreamDestroy(f.side);
         if (f.fs && f.fs != f.ms && f.fs != f.side) (void)hipStreamDestroy(f.fs);
-        hipEvent_t evs[] = {f.ev_fork, f.ev_start, f.ev_join, f.ev_shadow_done, f.ev_geom_done, f.ev_done, f.ev_prologue_done};
+        hipEvent_t evs[] = {f.ev_fork, f.ev_start, f.ev_join, f.ev_shadow_done, f.ev_geom_done, f.ev_done, f.ev_prologue_done, f.ev_fog_volume_done, f.ev_targets_free};
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1200,7 +1245,7 @@ int wr_render_frame_static(WrContext* ctx, const WrCameraUniform* camera, const 
     sf.ms = own.ms; sf.side = own.side; sf.fs = own.fs;
     sf.ev_fork = own.ev_fork; sf.ev_start = own.ev_start; sf.ev_join = own.ev_join;
     sf.ev_shadow_done = own.ev_shadow_done; sf.ev_geom_done = own.ev_geom_done; sf.ev_done = own.ev_done;
-    sf.ev_prologue_done = own.ev_prologue_done;
+    sf.ev_prologue_done = own.ev_prologue_done; sf.ev_fog_volume_done = own.ev_fog_volume_done; sf.ev_targets_free = own.ev_targets_free;
     Arena sizing;
     sizing.dry = true;
     if ((rc = carve_static_frame(ctx, sizing, &sf)) != WR_OK) return rc;
@@ -1226,7 +1271,7 @@ int wr_render_frame_static(WrContext* ctx, const WrCameraUniform* camera, const 
     if ((rc = begin_counted(ctx)) != WR_OK) return rc;
     FrameConsts fc = make_consts(ctx, camera, light, globals);
     if ((rc = frame_stages(ctx, &sf, fc, passes, true)) != WR_OK) return rc;
-    WR_HIP(hipEventRecord(sf.ev_done, sf.ms));
+    WR_HIP(hipEventRecord(sf.ev_done, sf.cur_ms));
     ctx->fr[0].submitted = true;
     WR_HIP(hipStreamWaitEvent(ctx->stream, sf.ev_done, 0));
     ctx->stream_has_work = true;  // (the next frame must not touch the shared streams' buffers early)
@@ -1249,7 +1294,7 @@ int wr_render_batch(WrContext* ctx, const WrCameraUniform* cameras, uint32_t cou
         if ((rc = frame_stages(ctx, f, fc, passes, shadows_every_frame || i == 0)) != WR_OK) return rc;
         if (device_frames)
             WR_HIP(hipMemcpyAsync((uint8_t*)device_frames + (size_t)i * frame_bytes, f->d_color, frame_bytes,
-                                  hipMemcpyDeviceToDevice, f->ms));
+                                  hipMemcpyDeviceToDevice, f->cur_ms));
         if ((rc = finish_frame(ctx, f)) != WR_OK) return rc;
     }
     return WR_OK;

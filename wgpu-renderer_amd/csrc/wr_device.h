@@ -213,8 +213,10 @@ WR_HD ClipVert clip_lerp(const ClipVert& in, const ClipVert& out, float t) {
 // New vertices are always interpolated from the inside end of the edge so that an edge
 // shared by two triangles clips to the same point from either side.
 // wgpu clips to the Vulkan volume 0<=z<=w (pass.rs:111 unclipped_depth: false).
-__host__ __device__ __attribute__((noinline)) inline int clip_polygon(ClipVert* poly, int n) {
-    ClipVert tmp[10];
+// (`tmp`: room for ten vertices; a kernel that clips a handful of triangles keeps both arrays in
+// LDS, where the many dependent accesses of the loops below cost a tenth of what they cost in
+// per-lane scratch memory.)
+__host__ __device__ __attribute__((noinline)) inline int clip_polygon_in(ClipVert* poly, ClipVert* tmp, int n) {
     for (int plane = 0; plane < 6; ++plane) {
         bool any_out = false;
         for (int i = 0; i < n; ++i) if (!(plane_dist(poly[i], plane) >= 0.0f)) any_out = true;
@@ -236,6 +238,10 @@ __host__ __device__ __attribute__((noinline)) inline int clip_polygon(ClipVert* 
         if (n < 3) return 0;
     }
     return n;
+}
+__host__ __device__ inline int clip_polygon(ClipVert* poly, int n) {
+    ClipVert tmp[10];
+    return clip_polygon_in(poly, tmp, n);
 }
 
 // Viewport transform, sub-pixel snap, cull, bounding box, depth plane and (shadow) bias of

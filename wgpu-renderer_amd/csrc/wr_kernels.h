@@ -227,15 +227,17 @@ struct SetupTarget {
 
 // Clip path: the fan triangles go to the overflow region of the record array, the parent
 // slot keeps where they are.  Rare, so its bins are counted without aggregation.
+// `work` (optional): room for twenty vertices the clipper may use instead of per-lane arrays.
 template <bool SHADOW>
 __device__ __attribute__((noinline)) void emit_clipped(const V4* c, uint32_t tri, uint32_t slot, const RasterWS& ws,
-                                                       const SetupTarget& tg) {
-    ClipVert poly[10];
+                                                       const SetupTarget& tg, ClipVert* work = nullptr) {
+    ClipVert own[20];
+    ClipVert* poly = work ? work : own;
     for (int k = 0; k < 3; ++k) {
         poly[k].x = c[k].x; poly[k].y = c[k].y; poly[k].z = c[k].z; poly[k].w = c[k].w;
         poly[k].b0 = k == 0 ? 1.0f : 0.0f; poly[k].b1 = k == 1 ? 1.0f : 0.0f; poly[k].b2 = k == 2 ? 1.0f : 0.0f;
     }
-    int n = clip_polygon(poly, 3);
+    int n = clip_polygon_in(poly, poly + 10, 3);
     Rec parent;
     parent.id = kRecInvalid;
     if (n >= 3) {
@@ -285,7 +287,7 @@ __device__ __attribute__((noinline)) void emit_clipped(const V4* c, uint32_t tri
 // do not weigh on the occupancy of the kernel that sets up the other 99 %.
 template <bool SHADOW, bool DEFER_CLIP>
 __device__ inline bool emit_triangle(bool have, const V4* c, uint32_t tri, uint32_t slot, const RasterWS& ws,
-                                     const SetupTarget& tg) {
+                                     const SetupTarget& tg, ClipVert* clip_work = nullptr) {
     Rec r;
     r.id = kRecInvalid;
     bool valid = false, deferred = false;
@@ -293,7 +295,7 @@ __device__ inline bool emit_triangle(bool have, const V4* c, uint32_t tri, uint3
         int cls = classify_triangle(c);
         if (cls == 2) {
             if (DEFER_CLIP) deferred = true;
-            else emit_clipped<SHADOW>(c, tri, slot, ws, tg);
+            else emit_clipped<SHADOW>(c, tri, slot, ws, tg, clip_work);
         } else {
             if (cls == 1) {
                 ClipVert cv[3];
@@ -377,12 +379,18 @@ __global__ __launch_bounds__(64) void k_setup_clip(const float4* clip, uint32_t 
 // The two 12-triangle helper models.  mode 0: light marker (light_debug.wgsl:12-21), its
 // records continue the geometry model's slots and ids; mode 1: fog volume (fog.wgsl:14-34)
 // into its own record array.  enabled == 0 only invalidates the slots.
-__global__ void k_setup_small(const float4* pos, const uint32_t* idx, uint32_t ntris, int mode, int enabled,
-                              uint32_t slot_base, RasterWS ws, FrameConsts fc) {
+// Most of the fog volume's triangles need the clipper when the camera is inside or near the
+// volume; its vertex arrays live in LDS here (in per-lane scratch memory the clipper's chains of
+// dependent accesses made this 12-triangle kernel take as long as the set-up of the whole scene).
+constexpr int kSmallTris = 16;  // triangles per workgroup (one wavefront)
+__global__ __launch_bounds__(64) void k_setup_small(const float4* pos, const uint32_t* idx, uint32_t ntris, int mode, int enabled,
+                                                    uint32_t slot_base, RasterWS ws, FrameConsts fc) {
     latency_bound_kernel();
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool have = t < ntris && enabled;
-    if (t < ntris && !enabled) {
+    __shared__ ClipVert s_clip[kSmallTris][20];
+    uint32_t t = blockIdx.x * kSmallTris + threadIdx.x;
+    const bool mine = threadIdx.x < (uint32_t)kSmallTris && t < ntris;
+    const bool have = mine && enabled;
+    if (mine && !enabled) {
         ws.bb[slot_base + t] = make_uint2(kBBInvalid, kBBNothing);
     }
     V4 c[3];
@@ -396,7 +404,7 @@ __global__ void k_setup_small(const float4* pos, const uint32_t* idx, uint32_t n
         }
     SetupTarget tg = setup_target(ws, 0, fc.W, fc.H, fc.geom_tile_rank, fc.geom_tile_world);
     tg.count = mode == 0;
-    emit_triangle<false, false>(have, c, slot_base + t, slot_base + t, ws, tg);
+    emit_triangle<false, false>(have, c, slot_base + t, slot_base + t, ws, tg, s_clip[threadIdx.x & (kSmallTris - 1)]);
 }
 
 // ------------------------------------------------------------------ binning
