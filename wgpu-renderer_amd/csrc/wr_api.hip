@@ -242,7 +242,7 @@ int alloc_ws(WrContext* ctx, Arena& ar, WsAlloc& w, uint32_t slots, uint32_t ovf
     WR_HIP(arena_take(ar, ws.recs, sizeof(Rec) * (size_t)layers * ((size_t)slots + ovf_cap)));
     WR_HIP(arena_take(ar, ws.bb, sizeof(uint2) * (size_t)layers * ((size_t)slots + ovf_cap)));
     WR_HIP(arena_take(ar, ws.betas, sizeof(float) * 9 * (size_t)layers * ovf_cap + 64));
-    w.counters_bytes = sizeof(uint32_t) * (2 * (size_t)layers + 2 * nb + extra_counters);
+    w.counters_bytes = sizeof(uint32_t) * (2 * (size_t)layers + 2 * nb + extra_counters + 1);
     WR_HIP(arena_take(ar, w.counters, w.counters_bytes));
     if (ar.dry) {  // sizing pass: no pointers to derive
         size_t dummy_bytes[3] = {sizeof(uint32_t) * (size_t)layers * slots, sizeof(uint32_t) * (nb + 1), sizeof(uint32_t) * ((size_t)items_cap + 1)};
@@ -254,6 +254,7 @@ int alloc_ws(WrContext* ctx, Arena& ar, WsAlloc& w, uint32_t slots, uint32_t ovf
     ws.bin_count = w.counters + layers;
     ws.bin_cursor = ws.bin_count + nb;
     ws.clip_count = ws.bin_cursor + nb;
+    ws.scan_total = w.counters + 2 * (size_t)layers + 2 * nb + extra_counters;
     WR_HIP(arena_take(ar, ws.clip_queue, sizeof(uint32_t) * (size_t)layers * slots));
     WR_HIP(arena_take(ar, ws.bin_offset, sizeof(uint32_t) * (nb + 1)));
     WR_HIP(arena_take(ar, ws.bin_items, sizeof(uint32_t) * ((size_t)items_cap + 1)));
@@ -555,7 +556,8 @@ int bin_and_raster(WrContext* ctx, FrameRes* f, hipStream_t st, WsAlloc& w, bool
                    hipEvent_t prev_done = nullptr) {
     RasterWS& ws = w.ws;
     uint32_t nrec = ws.slots + ws.ovf_cap;
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(kScanThreads), 0, st, ws);
+    const uint32_t nbins = (uint32_t)(ws.bins_x * ws.bins_y * ws.layers);
+    hipLaunchKernelGGL(k_scan, dim3((nbins + kScanThreads - 1) / kScanThreads), dim3(kScanThreads), 0, st, ws);
     hipLaunchKernelGGL(k_bin_fill, grid1(nrec, ws.layers), dim3(256), 0, st, ws, tr, tw);
     dim3 g((uint32_t)(ws.bins_x * ws.bins_y), (uint32_t)ws.layers, 1);
     if (prev_done) WR_HIP(hipStreamWaitEvent(st, prev_done, 0));  // the previous frame's fog tail reads the target this raster writes

@@ -48,6 +48,7 @@ struct RasterWS {
     uint32_t* bin_offset; // [layers * bins]
     uint32_t* bin_items;  // record indices, grouped by bin
     uint32_t* total_items;
+    uint32_t* scan_total;   // k_scan: entries of the item list handed out so far this frame
     uint32_t* err;
     uint32_t* clip_count; // [layers] triangles queued for the clipper this frame
     uint32_t* clip_queue; // [layers][slots] their triangle indices
@@ -416,6 +417,7 @@ __global__ __launch_bounds__(256) void k_bin_fill(RasterWS ws, int tile_rank, in
     latency_bound_kernel();
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t layer = blockIdx.y;
+    if (i == 0u && layer == 0u) *ws.total_items = *ws.scan_total;  // what the statistics report
     uint32_t ovf = ws.ovf_count[layer];
     if (ovf > ws.ovf_cap) ovf = ws.ovf_cap;
     const size_t stride = (size_t)ws.slots + ws.ovf_cap;
@@ -437,34 +439,37 @@ __global__ __launch_bounds__(256) void k_bin_fill(RasterWS ws, int tile_rank, in
     }
 }
 
-// Exclusive prefix sum of the bin counts (one workgroup; n is a few thousand to a few ten thousand).
-constexpr uint32_t kScanThreads = 256;  // small on purpose: has to find room next to long-running kernels of other frames
+// Gives every bin its range of the item list: bin_offset[b] = start of a range of bin_count[b]
+// entries.  The ranges need not follow the order of the bins, so each workgroup scans its 256
+// counts and takes the room for them with one atomic: two dozen independent workgroups instead of
+// one that walks all the counts, on a path every frame waits for twice.
+constexpr uint32_t kScanThreads = 256;
 __global__ __launch_bounds__(kScanThreads) void k_scan(RasterWS ws) {
     latency_bound_kernel();
-    __shared__ uint32_t part[kScanThreads];
-    uint32_t n = (uint32_t)(ws.bins_x * ws.bins_y * ws.layers);
-    uint32_t tid = threadIdx.x;
-    uint32_t chunk = (n + kScanThreads - 1u) / kScanThreads;
-    uint32_t beg = min(tid * chunk, n), end = min(beg + chunk, n);
-    uint32_t s = 0;
-    for (uint32_t k = beg; k < end; ++k) s += ws.bin_count[k];
-    part[tid] = s;
+    __shared__ uint32_t part[kScanThreads / 64], s_base;
+    const uint32_t n = (uint32_t)(ws.bins_x * ws.bins_y * ws.layers);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t i = blockIdx.x * kScanThreads + tid;
+    const uint32_t c = i < n ? ws.bin_count[i] : 0u;
+    uint32_t inc = c;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)inc, d);
+        if ((int)lane >= d) inc += v;
+    }
+    if (lane == 63u) part[wave] = inc;
     __syncthreads();
-    for (uint32_t d = 1; d < kScanThreads; d <<= 1) {
-        uint32_t v = tid >= d ? part[tid - d] : 0u;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    uint32_t before = 0u, total = 0u;
+    for (uint32_t w = 0; w < kScanThreads / 64; ++w) {
+        if (w < wave) before += part[w];
+        total += part[w];
     }
-    uint32_t run = part[tid] - s;
-    for (uint32_t k = beg; k < end; ++k) {
-        ws.bin_offset[k] = run;
-        run += ws.bin_count[k];
+    if (tid == 0u) {
+        const uint32_t base = total ? atomicAdd(ws.scan_total, total) : 0u;
+        s_base = base;
+        if ((unsigned long long)base + total > ws.items_cap) atomicOr(ws.err, kErrItemOverflow);
     }
-    if (tid == kScanThreads - 1u) {
-        *ws.total_items = part[kScanThreads - 1u];
-        if (part[kScanThreads - 1u] > ws.items_cap) atomicOr(ws.err, kErrItemOverflow);
-    }
+    __syncthreads();
+    if (i < n) ws.bin_offset[i] = s_base + before + (inc - c);
 }
 
 // ------------------------------------------------------------------ rasteriser
