@@ -279,19 +279,28 @@ def main():
         s1 = r1.stats()
         ev1 = int(s1.fog_noise_evals_view)
         r1.set_counting(False)
-        for i in range(5):
+        for i in range(20):
             r1.render_frame(cam, light, glob, passes)
         r1.sync()
+        # back to back: frames queued one behind the other on the one set of buffers (the next
+        # frame's vertex and triangle set-up runs next to the previous frame's fog tail)
         t1 = time.perf_counter()
-        for i in range(40):
+        for i in range(200):
             r1.render_frame(cam, light, glob, passes)
         r1.sync()
-        dt1 = (time.perf_counter() - t1) / 40
+        dt1 = (time.perf_counter() - t1) / 200
+        # alone: the host waits for every frame before it submits the next
+        t1 = time.perf_counter()
+        for i in range(50):
+            r1.render_frame(cam, light, glob, passes)
+            r1.sync()
+        lone = (time.perf_counter() - t1) / 50
         r1.set_profiling(2)
         for i in range(20):
             r1.render_frame(cam, light, glob, passes)
         s1 = r1.stats()
-        one_frame = {"frames_per_s": 1.0 / dt1, "view_ms": float(s1.ms_fog_march), "light_ms": float(s1.ms_fog_light_march), "evals_view": ev1}
+        one_frame = {"frames_per_s": 1.0 / dt1, "lone_frame_ms": lone * 1e3, "view_ms": float(s1.ms_fog_march),
+                     "light_ms": float(s1.ms_fog_light_march), "evals_view": ev1}
         r1.close()
 
     frames_per_step = 1 if args.workload != "tiles4k" else 1.0 / world  # tiles: all ranks share one frame
@@ -351,6 +360,9 @@ def main():
             "concurrency": f"launches of up to {in_flight} frames in flight overlap each other and the other stages, which stretches each launch",
             "one_frame_in_flight": None if not one_frame else {
                 "frames_per_s": one_frame["frames_per_s"],
+                "lone_frame_ms": one_frame["lone_frame_ms"],
+                "note": "frames_per_s: 200 frames queued back to back on one set of frame buffers, where a frame's geometry set-up overlaps "
+                        "the previous frame's fog tail; lone_frame_ms: submit, then wait, frame by frame (includes the host's submission)",
                 "kernel": "k_fog_noise_view<false>",
                 "launch_ms": one_frame["view_ms"],
                 "light_march_launch_ms": one_frame["light_ms"],

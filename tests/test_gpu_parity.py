@@ -521,7 +521,9 @@ def test_profiling_levels(small_scene, in_flight):
     assert st.profiled_frames == 5
     assert min(st.ms_shadow, st.ms_geometry, st.ms_shade, st.ms_fog, st.ms_fog_march) > 0.0
     assert st.ms_total >= max(st.ms_shadow, st.ms_geometry, st.ms_fog_march)
-    if in_flight == 1:  # the split march has a light-noise kernel of its own
+    if os.environ.get("WR_DEBUG_SCHEDULE"):  # (a forced fog schedule: either of the two below)
+        pass
+    elif in_flight == 1:  # the split march has a light-noise kernel of its own
         assert st.ms_fog_light_march > 0.2 * st.ms_fog_march
     else:
         assert st.ms_fog_light_march < 0.2 * st.ms_fog_march

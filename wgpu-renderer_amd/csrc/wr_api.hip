@@ -557,7 +557,8 @@ int bin_and_raster(WrContext* ctx, FrameRes* f, hipStream_t st, WsAlloc& w, bool
     RasterWS& ws = w.ws;
     uint32_t nrec = ws.slots + ws.ovf_cap;
     const uint32_t nbins = (uint32_t)(ws.bins_x * ws.bins_y * ws.layers);
-    hipLaunchKernelGGL(k_scan, dim3((nbins + kScanThreads - 1) / kScanThreads), dim3(kScanThreads), 0, st, ws);
+    if (ctx->nfr == 1) hipLaunchKernelGGL(k_scan, dim3((nbins + kScanThreads - 1) / kScanThreads), dim3(kScanThreads), 0, st, ws);
+    else hipLaunchKernelGGL(k_scan_one, dim3(1), dim3(kScanThreads), 0, st, ws);
     hipLaunchKernelGGL(k_bin_fill, grid1(nrec, ws.layers), dim3(256), 0, st, ws, tr, tw);
     dim3 g((uint32_t)(ws.bins_x * ws.bins_y), (uint32_t)ws.layers, 1);
     if (prev_done) WR_HIP(hipStreamWaitEvent(st, prev_done, 0));  // the previous frame's fog tail reads the target this raster writes

@@ -472,6 +472,36 @@ __global__ __launch_bounds__(kScanThreads) void k_scan(RasterWS ws) {
     if (i < n) ws.bin_offset[i] = s_base + before + (inc - c);
 }
 
+// Exclusive prefix sum of the bin counts in one workgroup (the version for frames that overlap:
+// it has to find room next to long-running kernels of other frames).
+__global__ __launch_bounds__(kScanThreads) void k_scan_one(RasterWS ws) {
+    latency_bound_kernel();
+    __shared__ uint32_t part[kScanThreads];
+    uint32_t n = (uint32_t)(ws.bins_x * ws.bins_y * ws.layers);
+    uint32_t tid = threadIdx.x;
+    uint32_t chunk = (n + kScanThreads - 1u) / kScanThreads;
+    uint32_t beg = min(tid * chunk, n), end = min(beg + chunk, n);
+    uint32_t s = 0;
+    for (uint32_t k = beg; k < end; ++k) s += ws.bin_count[k];
+    part[tid] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < kScanThreads; d <<= 1) {
+        uint32_t v = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - s;
+    for (uint32_t k = beg; k < end; ++k) {
+        ws.bin_offset[k] = run;
+        run += ws.bin_count[k];
+    }
+    if (tid == kScanThreads - 1u) {
+        *ws.scan_total = part[kScanThreads - 1u];
+        if (part[kScanThreads - 1u] > ws.items_cap) atomicOr(ws.err, kErrItemOverflow);
+    }
+}
+
 // ------------------------------------------------------------------ rasteriser
 // One workgroup per (bin, layer) resolves the bin in an LDS tile and writes it out once.
 // kRasterShadow: depth-only, LessEqual with bias -> plain min of the biased depth
