@@ -128,7 +128,10 @@ typedef struct WrConfig {
     void* stream;
     /* Frames in flight (the reference's surface keeps more than one frame in flight as well,
      * state.rs:631,806).  0 or 1: a frame's work is complete, as seen from `stream`, before
-     * anything queued on `stream` afterwards.  2 to 4: consecutive frames rotate through that
+     * anything queued on `stream` afterwards.  (Frames that follow each other on the library's
+     * own stream with nothing queued in between are ordered buffer by buffer, not frame by
+     * frame: a frame's vertex and triangle set-up may run while the previous frame's fog pass
+     * ends.  No buffer is written before its last reader is done.)  2 to 4: consecutive frames rotate through that
      * many sets of frame buffers (about 1.5 GB each at 1080p) and overlap on the device; a
      * frame's results are complete after wr_sync (every wr_read_* and wr_get_stats syncs), and
      * read-back / wr_color_device_ptr refer to the most recently submitted frame. */
