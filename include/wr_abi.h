@@ -327,8 +327,8 @@ int wr_comm_create(const uint8_t id[128], uint32_t rank, uint32_t world, int32_t
 int wr_comm_destroy(void* comm);
 
 /* enabled: 0 off; 1 records HIP events around every stage (a dozen per frame: a few per cent of a
- * frame that has the device to itself); 2 only those around the fog noise / march kernels, which
- * fills ms_fog_march and ms_fog_light_march and leaves the other times at zero. */
+ * frame that has the device to itself); 2 only the pair around the dominant kernel (the view
+ * noise or the march), which fills ms_fog_march and leaves the other times at zero. */
 int wr_set_profiling(WrContext* ctx, int enabled);
 /* enabled != 0 makes the next frames also count fragments / march steps with atomics
  * (slower, and a counted call does not overlap the frames before it; never enable it inside

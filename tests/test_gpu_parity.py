@@ -507,8 +507,8 @@ def test_resize_and_scene_reuse(tiny_scene):
 
 @pytest.mark.parametrize("in_flight", [1, 2])
 def test_profiling_levels(small_scene, in_flight):
-    """Level 1 times every stage, level 2 only the fog noise / march kernels (what a timed run can
-    afford); neither changes a pixel."""
+    """Level 1 times every stage, level 2 only the dominant kernel, the view noise or the march (what
+    a timed run can afford); neither changes a pixel."""
     w, h, s = 400, 225, 256
     cam, light, glob = default_inputs(w, h)
     plain = render_gpu(small_scene, cam, light, glob, abi.PASS_ALL, w, h, s)["color"]
@@ -532,7 +532,7 @@ def test_profiling_levels(small_scene, in_flight):
         r.render_frame(cam, light, glob, abi.PASS_ALL)
     st = r.stats()
     assert st.profiled_frames == 3 and st.ms_fog_march > 0.0
-    assert st.ms_shadow == st.ms_geometry == st.ms_shade == st.ms_fog == st.ms_total == 0.0
+    assert st.ms_shadow == st.ms_geometry == st.ms_shade == st.ms_fog == st.ms_total == st.ms_fog_light_march == 0.0
     assert np.array_equal(r.read_color(), plain)
     r.set_profiling(0)
     r.close()

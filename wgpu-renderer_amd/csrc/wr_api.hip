@@ -137,7 +137,6 @@ struct FrameRes {
     bool shadow_is_clear = true;
 
     VertexOut vout{};
-    float4* d_shadow_clip = nullptr;
     WsAlloc geom, shadow, fog;
     uint32_t* d_vis = nullptr;
     float* d_depth = nullptr;
@@ -281,7 +280,6 @@ void free_scene(WrContext* c) {
     dfree(c->d_mats); dfree(c->d_tex); dfree(c->d_texels);
     for (FrameRes& f : c->fr) {
         dfree(f.vout.clip); dfree(f.vout.v0); dfree(f.vout.v1); dfree(f.vout.v2); dfree(f.vout.v3);
-        dfree(f.d_shadow_clip);
         free_ws(f.geom); free_ws(f.shadow); free_ws(f.fog);
     }
 }
@@ -371,7 +369,6 @@ int alloc_frame_scene(WrContext* ctx, Arena& ar, FrameRes* f) {
     WR_HIP(arena_take(ar, f->vout.v1, sizeof(float4) * nvs));
     WR_HIP(arena_take(ar, f->vout.v2, sizeof(float4) * nvs));
     WR_HIP(arena_take(ar, f->vout.v3, sizeof(float4) * nvs));
-    WR_HIP(arena_take(ar, f->d_shadow_clip, sizeof(float4) * nvs * 6));
     int rc;
     // capacities in 64 bits: the sums pass 2^32 for meshes well below the 2^29-triangle limit
     {
@@ -576,11 +573,13 @@ int bin_and_raster(WrContext* ctx, FrameRes* f, hipStream_t st, WsAlloc& w, bool
 
 int shadow_stage(WrContext* ctx, FrameRes* f, hipStream_t st, const FrameConsts& fc, hipEvent_t prev_done = nullptr) {
     const ModelDev& g = ctx->dev[WR_MODEL_GEOMETRY];
-    hipLaunchKernelGGL(k_vs_shadow, grid1(g.nv, 6), dim3(256), 0, st, g.pos, g.nv, f->d_shadow_clip, fc);
-    hipLaunchKernelGGL(k_setup<true>, grid1(g.ntris, 6), dim3(256), 0, st, f->d_shadow_clip, g.nv, g.idx, g.ntris,
-                       f->shadow.ws, ctx->S, ctx->S, 0, 1);
-    hipLaunchKernelGGL(k_setup_clip<true>, dim3(128, 6, 1), dim3(64), 0, st, f->d_shadow_clip, g.nv, g.idx, f->shadow.ws,
-                       ctx->S, ctx->S, 0, 1);
+    ShadowXf xf;
+    memcpy(xf.model, fc.model_geom, sizeof(xf.model));
+    memcpy(xf.light, fc.light_m, sizeof(xf.light));
+    hipLaunchKernelGGL(k_setup<true>, grid1(g.ntris, 6), dim3(256), 0, st, g.pos, g.idx, g.ntris,
+                       f->shadow.ws, ctx->S, ctx->S, 0, 1, xf);
+    hipLaunchKernelGGL(k_setup_clip<true>, dim3(128, 6, 1), dim3(64), 0, st, g.pos, g.idx, f->shadow.ws,
+                       ctx->S, ctx->S, 0, 1, xf);
     return bin_and_raster(ctx, f, st, f->shadow, true, 0, 1, prev_done);
 }
 
@@ -731,7 +730,8 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
     const ModelDev& lm = ctx->dev[WR_MODEL_LIGHT_MARKER];
     const ModelDev& fm = ctx->dev[WR_MODEL_FOG_VOLUME];
     const bool prof = ctx->profiling == 1;        // all stage events
-    const bool prof_march = ctx->profiling != 0;  // the events around the dominant kernels
+    const bool prof_march = ctx->profiling != 0;  // the event pair around the dominant kernel (every event on the
+                                                  // fog stream is on the frame's longest chain: level 2 records these two only)
     hipEvent_t* ev = ctx->ev[ctx->ev_next];
     static const char* sched_env = getenv("WR_DEBUG_SCHEDULE");  // "split" / "mono": force a fog schedule
     const bool latency_schedule = sched_env ? sched_env[0] == 's' : ctx->nfr == 1;
@@ -810,10 +810,10 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
         // main stream: geometry + light marker -> visibility / depth
         VertexIn vin{g.pos, g.uv, g.nrm, g.tan, g.bit, g.nv};
         hipLaunchKernelGGL(k_vs_geometry, grid1(g.nv), dim3(256), 0, ms, vin, f->vout, fc);
-        hipLaunchKernelGGL(k_setup<false>, grid1(g.ntris, 1), dim3(256), 0, ms, f->vout.clip, g.nv, g.idx, g.ntris,
-                           f->geom.ws, ctx->W, ctx->H, fc.geom_tile_rank, fc.geom_tile_world);
-        hipLaunchKernelGGL(k_setup_clip<false>, dim3(256, 1, 1), dim3(64), 0, ms, f->vout.clip, g.nv, g.idx, f->geom.ws,
-                           ctx->W, ctx->H, fc.geom_tile_rank, fc.geom_tile_world);
+        hipLaunchKernelGGL(k_setup<false>, grid1(g.ntris, 1), dim3(256), 0, ms, f->vout.clip, g.idx, g.ntris,
+                           f->geom.ws, ctx->W, ctx->H, fc.geom_tile_rank, fc.geom_tile_world, ShadowXf{});
+        hipLaunchKernelGGL(k_setup_clip<false>, dim3(256, 1, 1), dim3(64), 0, ms, f->vout.clip, g.idx, f->geom.ws,
+                           ctx->W, ctx->H, fc.geom_tile_rank, fc.geom_tile_world, ShadowXf{});
         if (lm.ntris)
             hipLaunchKernelGGL(k_setup_small, dim3((lm.ntris + kSmallTris - 1) / kSmallTris), dim3(64), 0, ms, lm.pos, lm.idx, lm.ntris, 0,
                                (passes & WR_PASS_LIGHT_DEBUG) ? 1 : 0, g.ntris, f->geom.ws, fc);
@@ -900,7 +900,7 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
             WR_HIP(hipStreamWaitEvent(fog_st, f->ev_shadow_done, 0));
             if (ctx->counting) hipLaunchKernelGGL(k_fog_view_resolve<true>, dim3((item_groups + kResolveChunks - 1) / kResolveChunks), dim3(256), 0, fog_st, fa);
             else hipLaunchKernelGGL(k_fog_view_resolve<false>, dim3((item_groups + kResolveChunks - 1) / kResolveChunks), dim3(256), 0, fog_st, fa);
-            if (prof_march) WR_HIP(hipEventRecord(ev[10], fog_st));
+            if (prof) WR_HIP(hipEventRecord(ev[10], fog_st));
 #ifdef WR_DEV
             for (int l = 0; l < 16; ++l) fa.tables_noise.level[l].dbg_level = 256 + l;
 #endif
@@ -912,14 +912,15 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
             const dim3 mg((uint32_t)((npx + 63) / 64), 1, 1);
             if (ctx->counting) hipLaunchKernelGGL(k_fog_march<true>, mg, dim3(64), 0, fog_st, fa);
             else hipLaunchKernelGGL(k_fog_march<false>, mg, dim3(64), 0, fog_st, fa);
-            if (prof_march) { WR_HIP(hipEventRecord(ev[9], fog_st)); WR_HIP(hipEventRecord(ev[10], fog_st)); }
+            if (prof_march) WR_HIP(hipEventRecord(ev[9], fog_st));
+            if (prof) WR_HIP(hipEventRecord(ev[10], fog_st));
         }
     } else if (prof_march) {
         WR_HIP(hipEventRecord(ev[6], fog_st));
         WR_HIP(hipEventRecord(ev[9], fog_st));
-        WR_HIP(hipEventRecord(ev[10], fog_st));
+        if (prof) WR_HIP(hipEventRecord(ev[10], fog_st));
     }
-    if (prof_march) WR_HIP(hipEventRecord(ev[5], fog_st));
+    if (prof) WR_HIP(hipEventRecord(ev[5], fog_st));
     if (!swap_roles) WR_HIP(hipEventRecord(f->ev_join, fog_st));  // what the main stream waits for before the fog blend:
 
     // shading (reads the shadow maps; on another stream than the geometry pass it also waits for that)
@@ -1531,7 +1532,7 @@ int wr_get_stats(WrContext* ctx, WrFrameStats* out) {
         const int a[7] = {1, 0, 3, 8, 0, 6, 10}, b[7] = {2, 3, 4, 5, 7, 9, 5};  // shadow, geometry, shade, fog, frame, view noise, light noise
         double ms[7] = {0, 0, 0, 0, 0, 0, 0};
         for (int k = 0; k < ctx->ev_count; ++k)
-            for (int i = (ctx->ev_level == 2 ? 5 : 0); i < 7; ++i) {  // (level 2 recorded the last two pairs only)
+            for (int i = (ctx->ev_level == 2 ? 5 : 0); i < (ctx->ev_level == 2 ? 6 : 7); ++i) {  // (level 2 recorded the view noise / march pair only)
                 float t = 0.0f;
                 WR_HIP(hipEventElapsedTime(&t, ctx->ev[k][a[i]], ctx->ev[k][b[i]]));
                 ms[i] += t;

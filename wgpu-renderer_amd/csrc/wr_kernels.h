@@ -2,7 +2,7 @@
 //
 // Frame structure (kernels of one frame; the host runs the shadow pass and the fog pass up to
 // the march on a side stream, see frame_stages in wr_api.hip):
-//   shadow   : k_vs_shadow -> k_setup<true> (set-up + bin counts) -> k_setup_clip<true> ->
+//   shadow   : k_setup<true> (vertex stage + set-up + bin counts) -> k_setup_clip<true> ->
 //              k_scan -> k_bin_fill -> k_raster<kRasterShadow>   (6 cube faces as grid.y "layers")
 //   geometry : k_vs_geometry -> k_setup<false> -> k_setup_clip<false> (+ k_setup_small for the
 //              light marker) -> k_scan -> k_bin_fill -> k_raster<kRasterColor>
@@ -95,18 +95,6 @@ __global__ __launch_bounds__(256) void k_vs_geometry(VertexIn in, VertexOut out,
     out.v1[i] = make_float4(dot3(wn, w3), dot3(wt, lp), dot3(wb, lp), dot3(wn, lp));
     out.v2[i] = make_float4(dot3(wt, cp), dot3(wb, cp), dot3(wn, cp), wp.x);
     out.v3[i] = make_float4(wp.y, wp.z, wp.w, 0.0f);
-}
-
-// depth.wgsl:3-17, all six light_matrix_index values in one launch (grid.y = face)
-__global__ __launch_bounds__(256) void k_vs_shadow(const float4* pos, uint32_t nv, float4* clip, FrameConsts fc) {
-    latency_bound_kernel();
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nv) return;
-    uint32_t face = blockIdx.y;
-    float4 p = pos[i];
-    V4 wp = mat4_mul(fc.model_geom, V4{p.x, p.y, p.z, 1.0f});
-    V4 cl = mat4_mul(fc.light_m[face], wp);
-    clip[(size_t)face * nv + i] = make_float4(cl.x, cl.y, cl.z, cl.w);
 }
 
 // ------------------------------------------------------------------ triangle set-up
@@ -333,21 +321,36 @@ __device__ inline SetupTarget setup_target(const RasterWS& ws, uint32_t layer, i
     return tg;
 }
 
+// The shadow passes' vertex stage (depth.wgsl:3-17) is done by the triangle set-up itself: a
+// triangle transforms its three model-space positions with its face's light matrix.  The same
+// two products, in the same order, as a vertex kernel would do once per vertex and face: the
+// extra multiplications (a vertex is used by six triangles) cost less than writing and reading
+// 16 bytes per vertex and face, and the frame's chain of launches is one shorter.
+struct ShadowXf {
+    float model[16];     // InstanceRaw.model of the geometry model
+    float light[6][16];  // LightUniform.matrices
+};
+// Clip-space position of vertex i of layer `layer`: the stored one of the colour pass (`v` =
+// clip positions), or the transformed model-space position (`v` = positions) of a shadow face.
+template <bool SHADOW>
+__device__ inline V4 setup_vertex(const float4* v, uint32_t i, uint32_t layer, const ShadowXf& xf) {
+    const float4 p = v[i];
+    if (!SHADOW) return V4{p.x, p.y, p.z, p.w};
+    const V4 wp = mat4_mul(xf.model, V4{p.x, p.y, p.z, 1.0f});
+    return mat4_mul(xf.light[layer], wp);
+}
+
 // One thread per triangle of the geometry model; grid.y = layer (cube face for shadows).
 template <bool SHADOW>
-__global__ __launch_bounds__(256) void k_setup(const float4* clip, uint32_t nv, const uint32_t* idx, uint32_t ntris,
-                                               RasterWS ws, int W, int H, int tile_rank, int tile_world) {
+__global__ __launch_bounds__(256) void k_setup(const float4* verts, const uint32_t* idx, uint32_t ntris,
+                                               RasterWS ws, int W, int H, int tile_rank, int tile_world, ShadowXf xf) {
     latency_bound_kernel();
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const bool have = t < ntris;
     uint32_t layer = blockIdx.y;
-    const float4* cl = clip + (size_t)layer * nv;
     V4 c[3];
     if (have)
-        for (int k = 0; k < 3; ++k) {
-            float4 v = cl[idx[3 * t + k]];
-            c[k] = V4{v.x, v.y, v.z, v.w};
-        }
+        for (int k = 0; k < 3; ++k) c[k] = setup_vertex<SHADOW>(verts, idx[3 * t + k], layer, xf);
     __shared__ uint32_t s_cnt, s_base;
     SetupTarget tg = setup_target(ws, layer, W, H, tile_rank, tile_world);
     const bool deferred = emit_triangle<SHADOW, true>(have, c, t, t, ws, tg);
@@ -359,20 +362,16 @@ __global__ __launch_bounds__(256) void k_setup(const float4* clip, uint32_t nv, 
 // The triangles k_setup queued: clipped against the near, far and guard-band planes, their fan
 // triangles set up and counted into the bins.
 template <bool SHADOW>
-__global__ __launch_bounds__(64) void k_setup_clip(const float4* clip, uint32_t nv, const uint32_t* idx, RasterWS ws, int W, int H,
-                                                   int tile_rank, int tile_world) {
+__global__ __launch_bounds__(64) void k_setup_clip(const float4* verts, const uint32_t* idx, RasterWS ws, int W, int H,
+                                                   int tile_rank, int tile_world, ShadowXf xf) {
     latency_bound_kernel();
     const uint32_t layer = blockIdx.y;
     const uint32_t n = min(ws.clip_count[layer], ws.slots);
-    const float4* cl = clip + (size_t)layer * nv;
     SetupTarget tg = setup_target(ws, layer, W, H, tile_rank, tile_world);
     for (uint32_t k = blockIdx.x * 64u + threadIdx.x; k < n; k += gridDim.x * 64u) {
         const uint32_t t = ws.clip_queue[(size_t)layer * ws.slots + k];
         V4 c[3];
-        for (int j = 0; j < 3; ++j) {
-            float4 v = cl[idx[3 * t + j]];
-            c[j] = V4{v.x, v.y, v.z, v.w};
-        }
+        for (int j = 0; j < 3; ++j) c[j] = setup_vertex<SHADOW>(verts, idx[3 * t + j], layer, xf);
         emit_clipped<SHADOW>(c, t, t, ws, tg);
     }
 }
