@@ -328,7 +328,9 @@ int wr_comm_destroy(void* comm);
 
 /* enabled: 0 off; 1 records HIP events around every stage (a dozen per frame: a few per cent of a
  * frame that has the device to itself); 2 only the pair around the dominant kernel (the view
- * noise or the march), which fills ms_fog_march and leaves the other times at zero. */
+ * noise or the march), which fills ms_fog_march and leaves the other times at zero; with one
+ * frame in flight, where each event costs the frame about 1 %, level 2 records the pair for every
+ * fourth frame (WrFrameStats.profiled_frames counts the recorded ones). */
 int wr_set_profiling(WrContext* ctx, int enabled);
 /* enabled != 0 makes the next frames also count fragments / march steps with atomics
  * (slower, and a counted call does not overlap the frames before it; never enable it inside

@@ -47,7 +47,7 @@ for name, g, T, layers in (("shadow", 0, S, 6), ("geometry", 1, (W, H), 1)):
 dbg = read(8).view(np.uint64).reshape(3, 40000)
 nbg = ((W + 63) // 64) * ((H + 63) // 64)
 cntg = read(1)
-for mode, name, nb_ in ((0, "colour", nbg), (2, "layers", nbg), (1, "shadow", 6144 * 6)):
+for mode, name, nb_ in ((0, "colour", nbg), (2, "layers", nbg), (1, "shadow", 6144)):
     t = dbg[mode, :nb_].astype(np.float64) / 100.0  # microseconds
     o = np.argsort(-t)
     print(f"== raster {name}: sum {t.sum():.0f} us, max {t.max():.1f}, p99 {np.percentile(t,99):.1f}, p90 {np.percentile(t,90):.1f}, median {np.median(t):.1f}")

@@ -528,10 +528,10 @@ def test_profiling_levels(small_scene, in_flight):
     else:
         assert st.ms_fog_light_march < 0.2 * st.ms_fog_march
     r.set_profiling(2)
-    for _ in range(3):
+    for _ in range(8):
         r.render_frame(cam, light, glob, abi.PASS_ALL)
     st = r.stats()
-    assert st.profiled_frames == 3 and st.ms_fog_march > 0.0
+    assert st.profiled_frames == (2 if in_flight == 1 else 8) and st.ms_fog_march > 0.0  # (one in flight: every fourth frame)
     assert st.ms_shadow == st.ms_geometry == st.ms_shade == st.ms_fog == st.ms_total == st.ms_fog_light_march == 0.0
     assert np.array_equal(r.read_color(), plain)
     r.set_profiling(0)

@@ -44,6 +44,8 @@ constexpr int kColorRasterThreads = WR_COLOR_RASTER_THREADS;
 // bins (dozens of bin-filling triangles, one per wavefront at a time) set its length: eight
 // wavefronts per bin instead of four.  With frames overlapping the smaller workgroup is better.
 constexpr int kColorRasterThreadsAlone = 512;
+constexpr int kLayerRasterThreadsAlone = 1024;
+constexpr uint32_t kProfEveryAlone = 4;  // wr_set_profiling level 2, one frame in flight: frames per recorded event pair
 #ifndef WR_SHADOW_RASTER_THREADS
 #define WR_SHADOW_RASTER_THREADS 256
 #endif
@@ -200,6 +202,7 @@ struct WrContext {
     static constexpr int kEvPerFrame = 11;  // see frame_stages
     hipEvent_t ev[kEvFrames][kEvPerFrame] = {};
     int ev_count = 0;  // frames recorded since wr_set_profiling(1), saturates at kEvFrames
+    uint32_t prof_tick = 0;  // frames submitted since wr_set_profiling (level 2 samples them with one frame in flight)
     int ev_next = 0;
     WrFrameStats stats{};
 };
@@ -730,8 +733,10 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
     const ModelDev& lm = ctx->dev[WR_MODEL_LIGHT_MARKER];
     const ModelDev& fm = ctx->dev[WR_MODEL_FOG_VOLUME];
     const bool prof = ctx->profiling == 1;        // all stage events
-    const bool prof_march = ctx->profiling != 0;  // the event pair around the dominant kernel (every event on the
-                                                  // fog stream is on the frame's longest chain: level 2 records these two only)
+    // The event pair around the dominant kernel.  Every event on the fog stream is on the frame's
+    // longest chain (about 1 % of a frame each with one frame in flight): level 2 records these two
+    // only, and with one frame in flight only for every fourth frame.
+    const bool prof_march = ctx->profiling == 1 || (ctx->profiling == 2 && (ctx->nfr > 1 || (ctx->prof_tick++ % kProfEveryAlone) == 0));
     hipEvent_t* ev = ctx->ev[ctx->ev_next];
     static const char* sched_env = getenv("WR_DEBUG_SCHEDULE");  // "split" / "mono": force a fog schedule
     const bool latency_schedule = sched_env ? sched_env[0] == 's' : ctx->nfr == 1;
@@ -939,8 +944,15 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
     {
         const RasterWS& ws = f->geom.ws;
         LayerSink ls{f->blend.rp_slot, f->d_vis, f->blend.bin_flag, f->blend.lists, f->blend.list_count, f->blend.cap};
-        hipLaunchKernelGGL((k_raster<kRasterLayers, kColorRasterThreads>), dim3((uint32_t)(ws.bins_x * ws.bins_y), 1, 1), dim3(kColorRasterThreads), 0,
-                           shade_st, ws, ctx->W, ctx->H, (uint32_t*)nullptr, (float*)nullptr, fc.tile_rank, fc.tile_world, ls);
+        // (a frame that has the device to itself: the slowest bins, 140 us each with 256 threads,
+        // are the length of this launch, and a whole compute unit's worth of threads shortens them;
+        // frames overlapping: small workgroups find room sooner, 1111 against 1060 frames/s)
+        if (ctx->nfr == 1)
+            hipLaunchKernelGGL((k_raster<kRasterLayers, kLayerRasterThreadsAlone>), dim3((uint32_t)(ws.bins_x * ws.bins_y), 1, 1), dim3(kLayerRasterThreadsAlone), 0,
+                               shade_st, ws, ctx->W, ctx->H, (uint32_t*)nullptr, (float*)nullptr, fc.tile_rank, fc.tile_world, ls);
+        else
+            hipLaunchKernelGGL((k_raster<kRasterLayers, kColorRasterThreads>), dim3((uint32_t)(ws.bins_x * ws.bins_y), 1, 1), dim3(kColorRasterThreads), 0,
+                               shade_st, ws, ctx->W, ctx->H, (uint32_t*)nullptr, (float*)nullptr, fc.tile_rank, fc.tile_world, ls);
         const uint32_t slot_groups = (uint32_t)std::min<size_t>((npx + 255) / 256, 2048);
         hipLaunchKernelGGL(k_resolve, dim3(slot_groups), dim3(256), 0, shade_st, sa);
         if (ctx->counting) hipLaunchKernelGGL(k_replay_slow<true>, dim3(256), dim3(64), 0, shade_st, sa);
@@ -1514,6 +1526,7 @@ int wr_set_profiling(WrContext* ctx, int enabled) {
     ctx->ev_level = ctx->profiling;
     ctx->ev_count = 0;
     ctx->ev_next = 0;
+    ctx->prof_tick = 0;
     return WR_OK;
 }
 int wr_set_counting(WrContext* ctx, int enabled) {

@@ -768,6 +768,9 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
                 T[1] = u2f(s_tmax[threadIdx.x]);
             }
         }
+#ifdef WR_DEV
+        if (threadIdx.x == 0) g_dbg_cycles[MODE * 40000 + (int)gb] = wall_clock64() - dbg_t0;
+#endif
         return;
     }
     for (int i = threadIdx.x; i < kBin * kBin; i += kRasterThreads) {
