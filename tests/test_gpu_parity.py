@@ -345,6 +345,73 @@ def test_back_to_back_frames_on_one_set_of_buffers(small_scene, full_scene, size
     r.close()
 
 
+@pytest.mark.parametrize("seed,size", [(1, "small"), (2, "small"), (3, "small"), (4, "full")])
+def test_random_call_sequences_on_one_set_of_buffers(small_scene, full_scene, seed, size):
+    """One frame in flight: a random sequence of frames (random pose, time, passes), counted
+    frames, batches, frames into caller memory through the entry point that allocates nothing,
+    and read-backs at random places.  Whatever overlaps on the device, every frame that is looked
+    at equals the same frame rendered by a context that waits after every call."""
+    import random
+    import torch
+    rng = random.Random(seed)
+    sc, (w, h, s) = (small_scene, (400, 225, 256)) if size == "small" else (full_scene, (1920, 1080, 2048))
+    combos = [abi.PASS_ALL, abi.PASS_ALL, abi.PASS_ALL, abi.PASS_SHADOWS | abi.PASS_LIGHT_DEBUG, abi.PASS_FOG | abi.PASS_LIGHT_DEBUG,
+              abi.PASS_SHADOWS | abi.PASS_FOG, abi.PASS_LIGHT_DEBUG]
+
+    def inputs():
+        k = rng.randrange(64)
+        t = 1.0 + 0.1 * rng.randrange(60)
+        return default_inputs(w, h, pose=scene.flythrough_pose(k, 64))[0], abi.light_at_time(t), abi.global_uniforms(t, 1), rng.choice(combos)
+
+    ref = abi.Renderer(w, h, s)
+    ref.upload_scene(sc)
+    r = abi.Renderer(w, h, s, frames_in_flight=1)
+    r.upload_scene(sc)
+    # (both contexts draw shadow maps first: a frame without the shadow passes samples the last ones)
+    first = inputs()[:3] + (abi.PASS_ALL,)
+    ref.render_frame(*first); ref.sync()
+    r.render_frame(*first)
+    target = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    checked = 0
+    for step in range(60):
+        op = rng.choice(["frame"] * 6 + ["counted", "batch", "static" if size == "small" else "frame", "read"])
+        if op == "frame":
+            args = inputs()
+            ref.render_frame(*args); ref.sync()
+            r.render_frame(*args)
+        elif op == "counted":
+            args = inputs()
+            ref.set_counting(True); ref.render_frame(*args); a = ref.stats(); ref.set_counting(False)
+            r.set_counting(True); r.render_frame(*args); b = r.stats(); r.set_counting(False)
+            assert (a.fog_fragments, a.fog_noise_evals, a.shaded_fragments, a.replay_pixels) == \
+                   (b.fog_fragments, b.fog_noise_evals, b.shaded_fragments, b.replay_pixels), step
+        elif op == "batch":
+            cams = [inputs()[0] for _ in range(3)]
+            _, light, glob, passes = inputs()
+            for c in cams:
+                ref.render_frame(c, light, glob, passes); ref.sync()
+            r.render_batch(cams, light, glob, passes, shadows_every_frame=True)
+        elif op == "static":
+            args = inputs()
+            ref.render_frame(*args); ref.sync()
+            r.render_frame_static(*args, target.data_ptr())
+            r.sync(); torch.cuda.synchronize()
+            assert np.array_equal(target.cpu().numpy(), ref.read_color()), step
+            checked += 1
+            # (the shadow maps of a static frame live in its own buffer: both contexts redraw theirs)
+            again = inputs()[:3] + (abi.PASS_ALL,)
+            ref.render_frame(*again); ref.sync()
+            r.render_frame(*again)
+        if op == "read" or step % 9 == 8:
+            assert np.array_equal(r.read_color(), ref.read_color()), (step, op)
+            assert np.array_equal(r.read_depth(), ref.read_depth()), (step, op)
+            assert np.array_equal(r.read_shadow_map(), ref.read_shadow_map()), (step, op)
+            checked += 1
+    assert checked >= 6
+    ref.close()
+    r.close()
+
+
 @pytest.mark.parametrize("in_flight", [1, 3])
 def test_state_shared_between_frames_in_flight(small_scene, in_flight):
     """What frames share across the sets of frame buffers: a frame without shadow passes sees
