@@ -827,6 +827,10 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
     auto submit_fog_volume = [&]() {
         hipLaunchKernelGGL(k_setup_small, dim3((fm.ntris + kSmallTris - 1) / kSmallTris), dim3(64), 0, fs, fm.pos, fm.idx, fm.ntris, 1, 1, 0u, f->fog.ws, fc);
     };
+    // Submission takes the host about as long as the device needs for half a frame, so the
+    // order of the two independent chains matters: the one the frame's critical path starts
+    // with goes first (one frame in flight: geometry, which the view march waits for; frames
+    // overlapping: the shadow passes, the longer chain, which shading waits for).
     auto submit_geometry = [&]() -> int {
         // main stream: geometry + light marker -> visibility / depth
         VertexIn vin{g.pos, g.uv, g.nrm, g.tan, g.bit, g.nv};
