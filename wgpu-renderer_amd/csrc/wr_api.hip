@@ -271,7 +271,7 @@ void free_targets(WrContext* c) {
         dfree(f.d_vis); dfree(f.d_depth); dfree(f.d_color); dfree(f.d_fog_pixel); dfree(f.d_fog_ray); dfree(f.d_fog_res); dfree(f.d_fog_noise_view); dfree(f.d_fog_noise_light); dfree(f.d_fog_lit); dfree(f.d_fog_multi);
         BlendWS& b = f.blend;
         dfree(b.rp_slot); dfree(b.slot_pixel); dfree(b.counts); dfree(b.lists); dfree(b.list_count);
-        dfree(b.slow_slots); dfree(b.slot_frags); dfree(b.frag_item); dfree(b.frag_src);
+        dfree(b.slow_slots);
         b = BlendWS();
     }
 }
@@ -300,7 +300,7 @@ int alloc_frame_targets(WrContext* ctx, Arena& ar, FrameRes* f, bool color) {
     // lists are ever touched).
     BlendWS& b = f->blend;
     const size_t nbins = (size_t)((ctx->W + kBin - 1) / kBin) * (size_t)((ctx->H + kBin - 1) / kBin);
-    b.cap = (uint32_t)n; b.frag_cap = (uint32_t)n;
+    b.cap = (uint32_t)n;
     f->blend_clear_bytes = sizeof(uint32_t) * (4 + nbins);
     WR_HIP(arena_take(ar, b.rp_slot, n * 4));
     WR_HIP(arena_take(ar, b.slot_pixel, n * 4));
@@ -309,9 +309,6 @@ int alloc_frame_targets(WrContext* ctx, Arena& ar, FrameRes* f, bool color) {
     WR_HIP(arena_take(ar, b.lists, n * kReplayK * sizeof(uint2)));
     WR_HIP(arena_take(ar, b.list_count, n * 4));
     WR_HIP(arena_take(ar, b.slow_slots, n * 4));
-    WR_HIP(arena_take(ar, b.slot_frags, n * sizeof(uint2)));
-    WR_HIP(arena_take(ar, b.frag_item, n * sizeof(uint2)));
-    WR_HIP(arena_take(ar, b.frag_src, n * sizeof(float4)));
     WR_HIP(arena_take(ar, f->d_fog_pixel, n * 4));
     WR_HIP(arena_take(ar, f->d_fog_ray, n * sizeof(float4)));
     WR_HIP(arena_take(ar, f->d_fog_res, n * sizeof(float4)));
@@ -775,10 +772,10 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
     // Streams exchanging roles and nothing of the caller's to wait for: the shadow passes' set-up
     // touches only what the previous frame's shadow passes, earlier on the same stream, used, so it
     // need not wait for this frame's start, which is the end of the previous frame's shading.  It is
-    // let go when that shading is down to its last kernel, 70 us earlier, and is done by the time
-    // the previous frame lets go of the shadow maps.  (Let go earlier still, it runs in the middle of
-    // the previous frame and takes the slots of that frame's critical kernels: 930-950 against
-    // 1010 frames/s.)  Its counters are then cleared on its own stream.
+    // let go when that shading is down to its last, short kernel, and saves the 20 us an event
+    // takes to cross streams.  (Let go earlier, before the ordered blending or further back, it
+    // runs in the middle of the previous frame and takes the slots of that frame's critical
+    // kernels: 930-965 against 1030 frames/s.)  Its counters are then cleared on its own stream.
     const bool early_shadows = flipping && follows_own_frame;
     // every counter block of the frame's three raster work spaces and of the ordered blending, in
     // one launch, before the streams part
@@ -974,12 +971,10 @@ int frame_stages(WrContext* ctx, FrameRes* f, const FrameConsts& fc, uint32_t pa
             hipLaunchKernelGGL((k_raster<kRasterLayers, kColorRasterThreads>), dim3((uint32_t)(ws.bins_x * ws.bins_y), 1, 1), dim3(kColorRasterThreads), 0,
                                shade_st, ws, ctx->W, ctx->H, (uint32_t*)nullptr, (float*)nullptr, fc.tile_rank, fc.tile_world, ls);
         const uint32_t slot_groups = (uint32_t)std::min<size_t>((npx + 255) / 256, 2048);
-        hipLaunchKernelGGL(k_resolve, dim3(slot_groups), dim3(256), 0, shade_st, sa);
+        hipLaunchKernelGGL(k_resolve_shade, dim3(slot_groups), dim3(256), 0, shade_st, sa);
+        if (flipping) WR_HIP(hipEventRecord(f->ev_shade_tail, shade_st));
         if (ctx->counting) hipLaunchKernelGGL(k_replay_slow<true>, dim3(256), dim3(64), 0, shade_st, sa);
         else hipLaunchKernelGGL(k_replay_slow<false>, dim3(256), dim3(64), 0, shade_st, sa);
-        hipLaunchKernelGGL(k_shade_frags, dim3((uint32_t)std::min<size_t>((npx + 63) / 64, 16384)), dim3(64), 0, shade_st, sa);
-        if (flipping) WR_HIP(hipEventRecord(f->ev_shade_tail, shade_st));
-        hipLaunchKernelGGL(k_blend, dim3(slot_groups), dim3(256), 0, shade_st, sa);
     }
     if (prof) WR_HIP(hipEventRecord(ev[4], shade_st));
     if (swap_roles) WR_HIP(hipEventRecord(f->ev_join, shade_st));  // the fog pass, or (roles swapped) the shading

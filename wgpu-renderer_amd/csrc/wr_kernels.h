@@ -7,8 +7,7 @@
 //   geometry : k_vs_geometry -> k_setup<false> -> k_setup_clip<false> (+ k_setup_small for the
 //              light marker) -> k_scan -> k_bin_fill -> k_raster<kRasterColor>
 //              (visibility + depth buffers)
-//   shade    : k_shade -> k_raster<kRasterLayers> -> k_resolve -> k_replay_slow ->
-//              k_shade_frags -> k_blend
+//   shade    : k_shade -> k_raster<kRasterLayers> -> k_resolve_shade -> k_replay_slow
 //              (deferred pbr.wgsl fragment stage; ordered blending of translucent fronts)
 //   fog      : k_setup_small(fog) -> k_fog_tables -> k_fog_setup -> k_fog_noise_view ->
 //              k_fog_view_resolve -> k_fog_noise_light -> k_fog_shade_blend (+ k_fog_multi)
@@ -794,21 +793,17 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
 
 // ------------------------------------------------------------------ deferred shading
 // Work space of the ordered-blend kernels (k_shade flags, k_raster<kRasterLayers> collects,
-// k_resolve orders, k_shade_frags shades, k_blend blends).
+// k_resolve_shade orders, shades and blends).
 struct BlendWS {
     uint32_t* rp_slot;     // [H][W] list slot + 1 of a flagged pixel, else 0
     uint32_t* slot_pixel;  // [cap] pixel index of a slot
-    uint32_t* counts;      // [0] flagged pixels, [1] fragments to shade, [2] slow pixels; cleared every frame
+    uint32_t* counts;      // [0] flagged pixels, [2] slow pixels; cleared every frame
     uint32_t* bin_flag;    // [bins] bin holds a flagged pixel; cleared every frame
     uint2* lists;          // [kReplayK][cap] (id, depth bits) of the fragments covering a flagged pixel
     uint32_t* list_count;  // [cap]
     uint32_t* slow_slots;  // [cap] slots left to k_replay_slow
-    uint2* slot_frags;     // [cap] first fragment item, number of items (kSlotDone: colour already final)
-    uint2* frag_item;      // [frag_cap] (slot, id), a pixel's items adjacent and in draw order
-    float4* frag_src;      // [frag_cap] shaded fragment colour
-    uint32_t cap, frag_cap;
+    uint32_t cap;
 };
-constexpr uint32_t kSlotDone = 0xFFFFFFFFu;
 
 struct ShadeArgs {
     FrameConsts fc;
@@ -995,38 +990,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     if (threadIdx.x == 0) a.bw.bin_flag[bin] = 1u;
 }
 
-// Ordered blending, step 2 (step 1 is k_raster<kRasterLayers>): one thread per flagged
+// Ordered blending, steps 2 to 4 (step 1 is k_raster<kRasterLayers>): one thread per flagged
 // pixel.  Sorted by triangle id the collected fragments give the draw order, and a running
 // minimum over depth gives those that passed the depth test when drawn.  The ones from the
 // last fragment whose material cannot be translucent onwards (it replaced everything under
-// it) become items for k_shade_frags.  Pixels covered by more than kReplayK fragments, or
-// left without room in the item buffer, are queued for k_replay_slow.
-__global__ __launch_bounds__(256) void k_resolve(ShadeArgs a) {
+// it) are shaded one after the other (pbr.wgsl's fs_main; the light marker, drawn with
+// REPLACE, has a constant colour: light_debug.wgsl:23-26) and blended over the clear colour in
+// draw order (geometry: SrcAlpha/OneMinusSrcAlpha, state.rs:465-467; light marker: REPLACE,
+// state.rs:480-482).  Pixels covered by more than kReplayK fragments are queued for
+// k_replay_slow.  (Three kernels once: ordering, one lane per fragment to shade, blending.  In
+// one, a frame's chain is two launches and 40 us shorter and 48 bytes per pixel of buffers are
+// gone; that a lane now shades its pixel's two or three fragments in turn costs less.)
+__global__ __launch_bounds__(256) void k_resolve_shade(ShadeArgs a) {
     latency_bound_kernel();
-    __shared__ uint32_t s_cnt, s_base;
+    __shared__ float s_tab[768];
+    __shared__ uint32_t s_ids[kReplayK][256];  // the fragments a thread will shade, in draw order
     const int tid = threadIdx.x;
     const BlendWS& bw = a.bw;
     const uint32_t nslots = min(bw.counts[0], bw.cap);
-    for (uint32_t s0 = blockIdx.x * 256u; s0 < nslots; s0 += gridDim.x * 256u) {
-        const uint32_t s = s0 + (uint32_t)tid;
-        const bool live = s < nslots;
-        const uint32_t cnt = live ? bw.list_count[s] : 0u;
-        bool slow = cnt > (uint32_t)kReplayK;
-        // The list lives in registers (the sort is a fixed network, every index a constant), so
-        // the kernel needs no LDS to speak of and its workgroups fit next to anything.
-        uint32_t id[kReplayK];
-        float z[kReplayK];
-        uint32_t keep = 0u;      // bit i: entry i of the sorted list passed the depth test when drawn
-        int first_kept = kReplayK;  // index of the entry the blending starts from
-        uint32_t want = 0u;
-        if (live && !slow) {
-            // the whole list in flight at once; empty entries sort to the end
+    if (blockIdx.x * 256u >= nslots) return;
+    stage_color_tables(s_tab, a.tables);
+    ColorTables ct{s_tab};
+    for (uint32_t s = blockIdx.x * 256u + (uint32_t)tid; s < nslots; s += gridDim.x * 256u) {
+        const uint32_t cnt = bw.list_count[s];
+        if (cnt > (uint32_t)kReplayK) {
+            bw.slow_slots[atomicAdd(&bw.counts[2], 1u)] = s;
+            continue;
+        }
+        uint32_t nkeep = 0u;
+        {
+            uint32_t id[kReplayK];
+            float z[kReplayK];
 #pragma unroll
             for (int i = 0; i < kReplayK; ++i) {
                 const uint2 q = (uint32_t)i < cnt ? bw.lists[(size_t)i * bw.cap + s] : make_uint2(0xFFFFFFFFu, 0u);
                 id[i] = q.x; z[i] = u2f(q.y);
             }
-            // ascending id = draw order: Batcher's odd-even merge sort for 16 keys (63 exchanges)
             static_assert(kReplayK == 16, "the sorting network below is the one for 16 keys");
 #define CX(x, y)                                                                  \
     {                                                                             \
@@ -1044,13 +1043,12 @@ __global__ __launch_bounds__(256) void k_resolve(ShadeArgs a) {
             CX(6, 10) CX(7, 11) CX(2, 4) CX(3, 5) CX(6, 8) CX(7, 9) CX(10, 12) CX(11, 13)
             CX(1, 2) CX(3, 4) CX(5, 6) CX(7, 8) CX(9, 10) CX(11, 12) CX(13, 14)
 #undef CX
-            // a running minimum over depth gives the fragments that passed depth test Less when drawn
+            uint32_t keep = 0u;
             float d = 1.0f;
 #pragma unroll
             for (int i = 0; i < kReplayK; ++i)
                 if ((uint32_t)i < cnt && z[i] < d) { d = z[i]; keep |= 1u << i; }
-            // blending starts at the last kept fragment whose material cannot be translucent (it
-            // replaced everything under it), else at the first kept one
+            int first_kept = kReplayK;
             bool found = false;
 #pragma unroll
             for (int i = kReplayK - 1; i >= 0; --i)
@@ -1059,28 +1057,33 @@ __global__ __launch_bounds__(256) void k_resolve(ShadeArgs a) {
                     first_kept = i;
                     if (tri >= a.ntris_geom || a.mats[a.tri_mat[tri]].opaque) found = true;
                 }
-            want = (uint32_t)__builtin_popcount(keep >> (first_kept < kReplayK ? first_kept : 0)) * (keep ? 1u : 0u);
-        }
-        // room in the item buffer
-        const uint32_t first = group_append(&bw.counts[1], want, &s_cnt, &s_base);
-        if ((unsigned long long)first + want > bw.frag_cap) slow = true;
-        if (!live) continue;
-        if (slow) {
-            // items it was given but cannot use are marked, so that k_shade_frags skips them
-            for (uint32_t k = 0; k < want && first + k < bw.frag_cap; ++k) bw.frag_item[first + k] = make_uint2(kSlotDone, 0u);
-            bw.slow_slots[atomicAdd(&bw.counts[2], 1u)] = s;
-            bw.slot_frags[s] = make_uint2(0u, kSlotDone);
-            continue;
-        }
-        uint32_t k = 0;
 #pragma unroll
-        for (int i = 0; i < kReplayK; ++i)
-            if (i >= first_kept && ((keep >> i) & 1u)) bw.frag_item[first + k++] = make_uint2(s, id[i]);
-        bw.slot_frags[s] = make_uint2(first, want);
+            for (int i = 0; i < kReplayK; ++i)
+                if (i >= first_kept && ((keep >> i) & 1u)) s_ids[nkeep++][tid] = id[i];
+        }
+        const uint32_t pi = bw.slot_pixel[s];
+        const int px = (int)(pi % (uint32_t)a.fc.W), py = (int)(pi / (uint32_t)a.fc.W);
+        uint32_t col = 0xFF000000u;
+        for (uint32_t k = 0; k < nkeep; ++k) {
+            const uint32_t fid = s_ids[k][tid];
+            const uint32_t tri = fid >> 3;
+            V4 src = V4{a.fc.light_color[0], a.fc.light_color[1], a.fc.light_color[2], 1.0f};
+            if (tri < a.ntris_geom) {
+                const float* beta;
+                Rec r = fetch_rec(a.ws, fid, beta);
+                Edges e;
+                make_edges(r, e);
+                int64_t E[3];
+                edge_eval(e, px, py, E);
+                src = shade_fragment<false>(a, s_tab, r, beta, e, tri, px, py, E);
+            }
+            col = blend_pack(ct, col, src, tri < a.ntris_geom);
+        }
+        a.color[pi] = col;
     }
 }
 
-// Ordered blending of the pixels k_resolve queued: the general, slow method.
+// Ordered blending of the pixels k_resolve_shade queued: the general, slow method.
 template <bool COUNT>
 __global__ __launch_bounds__(64) void k_replay_slow(ShadeArgs a) {
     latency_bound_kernel();
@@ -1091,59 +1094,6 @@ __global__ __launch_bounds__(64) void k_replay_slow(ShadeArgs a) {
         const uint32_t pi = bw.slot_pixel[bw.slow_slots[k]];
         if (COUNT) atomicAdd(&a.counters[4], 1ull);
         a.color[pi] = replay_pixel(a, (int)(pi % (uint32_t)a.fc.W), (int)(pi / (uint32_t)a.fc.W));
-    }
-}
-
-// Ordered blending, step 3: one thread per fragment item runs pbr.wgsl's fs_main (the light
-// marker, drawn with REPLACE, has a constant colour: light_debug.wgsl:23-26).
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_shade_frags(ShadeArgs a) {
-    latency_bound_kernel();
-    __shared__ float s_tab[768];
-    const BlendWS& bw = a.bw;
-    if (blockIdx.x * 64u >= min(bw.counts[1], bw.frag_cap)) return;
-    stage_color_tables(s_tab, a.tables);
-    const uint32_t n = min(bw.counts[1], bw.frag_cap);
-    for (uint32_t f = blockIdx.x * 64u + threadIdx.x; f < n; f += gridDim.x * 64u) {
-        const uint2 it = bw.frag_item[f];
-        if (it.x == kSlotDone) continue;
-        const uint32_t pi = bw.slot_pixel[it.x];
-        const int px = (int)(pi % (uint32_t)a.fc.W), py = (int)(pi / (uint32_t)a.fc.W);
-        const uint32_t tri = it.y >> 3;
-        V4 src = V4{a.fc.light_color[0], a.fc.light_color[1], a.fc.light_color[2], 1.0f};
-        if (tri < a.ntris_geom) {
-            const float* beta;
-            Rec r = fetch_rec(a.ws, it.y, beta);
-            Edges e;
-            make_edges(r, e);
-            int64_t E[3];
-            edge_eval(e, px, py, E);
-            src = shade_fragment<false>(a, s_tab, r, beta, e, tri, px, py, E);
-        }
-        bw.frag_src[f] = make_float4(src.x, src.y, src.z, src.w);
-    }
-}
-
-// Ordered blending, step 4: blends a pixel's shaded fragments over the clear colour in draw
-// order (geometry: SrcAlpha/OneMinusSrcAlpha, state.rs:465-467; light marker: REPLACE,
-// state.rs:480-482).
-__global__ __launch_bounds__(256) void k_blend(ShadeArgs a) {
-    latency_bound_kernel();
-    __shared__ float s_tab[768];
-    const BlendWS& bw = a.bw;
-    const uint32_t nslots = min(bw.counts[0], bw.cap);
-    if (blockIdx.x * 256u >= nslots) return;
-    stage_color_tables(s_tab, a.tables);
-    ColorTables ct{s_tab};
-    for (uint32_t s = blockIdx.x * 256u + threadIdx.x; s < nslots; s += gridDim.x * 256u) {
-        const uint2 fr = bw.slot_frags[s];
-        if (fr.y == kSlotDone) continue;
-        uint32_t col = 0xFF000000u;
-        for (uint32_t k = 0; k < fr.y; ++k) {
-            const float4 c = bw.frag_src[fr.x + k];
-            const bool geometry = (bw.frag_item[fr.x + k].y >> 3) < a.ntris_geom;
-            col = blend_pack(ct, col, V4{c.x, c.y, c.z, c.w}, geometry);
-        }
-        a.color[bw.slot_pixel[s]] = col;
     }
 }
 
