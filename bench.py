@@ -347,6 +347,9 @@ def main():
             "kernel": kernel + (" (fog.wgsl fragment stage: noise of the view-march steps, 2 x 8 octaves of value noise each)" if latency_schedule
                                 else " (fog.wgsl fragment stage: two ray marches through 2 x 8 octaves of value noise)"),
             "bound": "valu",
+            "bound_note": "FP32 vector ALU: no stage of the path is a contraction, so no MFMA; the f32 vector peak priced against "
+                          "equals the dense f32 MFMA peak; on straight-line v_fmac_f32 code this device issues 0.82-0.91 of the nominal "
+                          "rate executed.issue_frac is priced against (scripts/dev_ifetch_bench.hip)",
             "achieved": (fog_flops / fog_s) / 1e12 if fog_s > 0 else None,
             "peak": PEAK_FP32_TFLOPS,
             "unit": "TFLOP/s",
