@@ -575,6 +575,17 @@ __device__ inline void raster_emit(const Rec& r, float z, int li, unsigned long 
 #ifndef WR_RASTER_LANE_AREA
 #define WR_RASTER_LANE_AREA 128
 #endif
+#ifndef WR_RASTER_LANE_AREA_LAYERS
+#define WR_RASTER_LANE_AREA_LAYERS 64
+#endif
+// Largest part of a bin (pixels of the clipped box) a triangle may cover and still be rasterised
+// by the lane that fetched it.  The layers walk appends to lists in global memory for every
+// covered flagged pixel, a lane's serial loop over its box is slower there, and the box at which
+// a wavefront per triangle pays is smaller: 81 -> 63 us alone with 64 instead of 128 (76 with 32),
+// while the colour and shadow walks are fastest with 128 (63 / 72 / 98 us and 162 / 165 / 168 us
+// with 128 / 64 / 32).
+template <int MODE>
+constexpr int raster_lane_area() { return MODE == 2 ? WR_RASTER_LANE_AREA_LAYERS : WR_RASTER_LANE_AREA; }
 // THREADS is chosen by the host per target; both targets use 256.  The shadow faces have 6144
 // mostly short lists, where small workgroups keep more bins in flight per CU.  The colour
 // target has few bins, some with thousands of triangles, where 1024 threads sharing the tile
@@ -652,7 +663,7 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
                 }
             }
             if (!wanted) {
-            } else if (fw <= 64 * 256 && fh <= 64 * 256 && (x1 - x0 + 1) * (y1 - y0 + 1) <= WR_RASTER_LANE_AREA) {
+            } else if (fw <= 64 * 256 && fh <= 64 * 256 && (x1 - x0 + 1) * (y1 - y0 + 1) <= raster_lane_area<MODE>()) {
                 // The triangle's vertices span at most 64x64 pixels, so every edge function
                 // stays below 2^30 over its box and can be stepped in 32-bit integers; the
                 // values are the same integers the 64-bit evaluation gives.
