@@ -283,7 +283,7 @@ void* wr_color_device_ptr(WrContext* ctx);
 int wr_pack_owned_bins(WrContext* ctx, void* device_dst, uint32_t* out_bins);
 int wr_scatter_bins(WrContext* ctx, const void* device_src, uint32_t rank, uint32_t world);
 
-/* ---- gathering a bin-sharded frame (BASELINE configs[3]: one frame, its 64x64 bins dealt
+/* ---- gathering a bin-sharded frame (one 3840x2160 frame, its 64x64 bins dealt
  * round-robin over the ranks).  No counterpart in the reference, which is single-GPU; the
  * frame arriving complete on one device stands for its `surface_texture.present()`
  * (state.rs:806).

@@ -1,7 +1,7 @@
 """Generates the committed fixtures under tests/golden/ from the CPU oracle:
   oracle_vectors.json      known-answer vectors of the shader arithmetic (sine, noise, BRDF,
                            ambient term, depth_to_linear, sRGB) and of triangle set-up
-  cube_frame_160x90.npz    BASELINE config 1 (Cube.glb as geometry, PBS only) at reduced size
+  cube_frame_160x90.npz    the single-cube scene (Cube.glb as geometry, PBS only) at reduced size
   standin_frame_192x108.npz  small Sponza stand-in frame with shadows + fog
 The reference has no golden data of its own, so these pin the oracle against regressions
 and give the GPU tests fixed expected outputs; they are outputs of this repository's

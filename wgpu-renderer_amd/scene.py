@@ -346,7 +346,7 @@ def sponza_standin(detail: float = 1.0, tex_size: int = 1024, n_materials: int =
 
 
 def cube_scene(textures: Optional[List[Tuple[np.ndarray, bool]]] = None, tex_size: int = 64) -> Scene:
-    """BASELINE config 1: Cube.glb as the geometry model, instance scale 100 at the origin.
+    """The reference's smallest scene: Cube.glb as the geometry model, instance scale 100 at the origin.
     Without `textures` (base colour, metallic-roughness as decoded from the GLB) a small
     procedural pair is used.  Cube.glb has no normal texture, so the normal slot falls back
     to image 0 read as linear (resources.rs:74,89)."""
