@@ -184,6 +184,8 @@ extern "C" {
     pub fn wr_comm_unique_id(id: *mut u8) -> c_int;
     pub fn wr_comm_create(id: *const u8, rank: u32, world: u32, device: i32, out_comm: *mut *mut c_void) -> c_int;
     pub fn wr_comm_destroy(comm: *mut c_void) -> c_int;
+    pub fn wr_comm_transport(comm: *mut c_void, out: *mut WrTransport) -> c_int;
+    pub fn wr_comm_library_path(path: *mut c_char, cap: usize) -> c_int;
 
     // ---- timing and counters
     pub fn wr_set_profiling(ctx: *mut WrContext, enabled: c_int) -> c_int;

@@ -235,21 +235,25 @@ int wr_render_batch(WrContext* ctx, const WrCameraUniform* cameras, uint32_t cou
                     const WrLightUniform* light, const WrGlobalUniforms* globals,
                     uint32_t passes, int shadows_every_frame, void* device_frames);
 
-/* wr_render_frame for callers that cannot allocate device memory (code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
- * reference.  Renders the same frame as wr_render_frame, bit for bit, with every work buffer
- * of the frame (shadow maps, bin lists, visibility, ordered-blend lists, fog items, noise
- * tables) inside one file-scope device array of 96 MiB that each GPU using the library holds
- * until the process ends; the finished RGBA8 frame goes to `device_color` (device memory,
- * width*height*4 bytes, brought by the caller).  Calls no hipMalloc / hipFree.  The scene must
- * already be resident: the first wr_render_frame after an upload or resize makes it so,
- * otherwise WR_ERR_NO_SCENE.  A target and scene whose work buffers do not fit the array
+/* wr_render_frame for callers that cannot allocate device memory (tight serving loops,
+ * harnesses that forbid hipMalloc, hosts that must have every allocation behind them before a
+ * region that may not allocate begins).  No counterpart in the reference.  Renders the same
+ * frame as wr_render_frame, bit for bit, with every work buffer of the frame (shadow maps, bin
+ * lists, visibility, ordered-blend lists, fog items, noise tables) inside one file-scope device
+ * array of 96 MiB that each GPU using the library holds until the process ends; the finished
+ * RGBA8 frame goes to `device_color` (device memory, width*height*4 bytes, brought by the
+ * caller).  Calls no hipMalloc / hipFree.  The call itself cannot be recorded into a HIP graph:
+ * it forks onto the library's streams and waits on events of earlier, unrecorded frames.  The
+ * scene must already be resident: the first wr_render_frame after an upload or resize makes it
+ * so, otherwise WR_ERR_NO_SCENE.  A target and scene whose work buffers do not fit the array
  * (roughly: beyond 320x180 pixels with 256^2 shadow faces and 16k triangles; the error text
  * gives the exact need) return WR_ERR_CAPACITY; bin-sharded contexts return
- * WR_ERR_UNSUPPORTED.  All calls on one GPU share that GPU's array, from any context: calls
- * that overlap on one GPU race.  Results are complete, as seen from the context's stream,
- * when the call's work has run (wr_sync); wr_read_* keep referring to wr_render_frame's
- * buffers. */
+ * WR_ERR_UNSUPPORTED.  All calls on one GPU share that GPU's array, from any context and any
+ * host thread: the library orders them on the device, each behind the one submitted before it
+ * (an event per GPU; submission is under a mutex), so they never overlap there; anything else
+ * a caller runs next to them is untouched.  Results are complete, as seen from the context's
+ * stream, when the call's work has run (wr_sync); wr_read_* keep referring to
+ * wr_render_frame's buffers; a list overflow of a static frame is reported by wr_sync as such. */
 int wr_render_frame_static(WrContext* ctx, const WrCameraUniform* camera, const WrLightUniform* light,
                            const WrGlobalUniforms* globals, uint32_t passes, void* device_color);
 
@@ -325,6 +329,13 @@ int wr_gather_bins(WrContext* ctx, void* nccl_comm, uint32_t root);
 int wr_comm_unique_id(uint8_t id[128]);
 int wr_comm_create(const uint8_t id[128], uint32_t rank, uint32_t world, int32_t device, void** out_comm);
 int wr_comm_destroy(void* comm);
+/* The transfers wr_gather_bins uses, for hosts that compose their own exchanges from them:
+ * fills `out` with grouped ncclSend / ncclRecv on `comm` (bytes as ncclUint8).  Valid until
+ * wr_comm_destroy(comm). */
+int wr_comm_transport(void* comm, WrTransport* out);
+/* File name of the RCCL library the loader bound (a process can hold more than one build under
+ * the same soname, e.g. a framework's bundled copy next to /opt/rocm's): diagnostics. */
+int wr_comm_library_path(char* path, size_t cap);
 
 /* enabled: 0 off; 1 records HIP events around every stage (a dozen per frame: a few per cent of a
  * frame that has the device to itself); 2 only the pair around the dominant kernel (the view

@@ -367,7 +367,8 @@ def test_random_call_sequences_on_one_set_of_buffers(small_scene, full_scene, se
     ref.upload_scene(sc)
     r = abi.Renderer(w, h, s, frames_in_flight=1)
     r.upload_scene(sc)
-    # (both contexts draw shadow maps first: a frame without the shadow passes samples the last ones)
+    # (a frame without the shadow passes samples cleared maps, whatever was drawn before; both
+    # contexts start from a frame with every pass all the same, so that every buffer has been used)
     first = inputs()[:3] + (abi.PASS_ALL,)
     ref.render_frame(*first); ref.sync()
     r.render_frame(*first)

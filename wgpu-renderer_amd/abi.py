@@ -140,6 +140,8 @@ SYMBOLS = {
     "wr_comm_unique_id": (C.c_int, [_P]),
     "wr_comm_create": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_int32, C.POINTER(_P)]),
     "wr_comm_destroy": (C.c_int, [_P]),
+    "wr_comm_transport": (C.c_int, [_P, _P]),
+    "wr_comm_library_path": (C.c_int, [C.c_char_p, C.c_size_t]),
     "wr_glb_parse": (C.c_int, [_P, C.c_size_t, C.POINTER(_P), C.c_char_p, C.c_size_t]),
     "wr_glb_load_file": (C.c_int, [C.c_char_p, C.POINTER(_P), C.c_char_p, C.c_size_t]),
     "wr_glb_free": (None, [_P]),
@@ -253,6 +255,24 @@ def comm_create(uid: bytes, rank: int, world: int, device: int) -> int:
 
 def comm_destroy(comm: int) -> None:
     load_library().wr_comm_destroy(comm)
+
+
+def comm_transport(comm: int) -> "Transport":
+    """wr_comm_transport: the grouped RCCL send / recv wr_gather_bins uses, as a WrTransport."""
+    tp = Transport()
+    rc = load_library().wr_comm_transport(comm, C.byref(tp))
+    if rc != WR_OK:
+        raise WrError(rc, "wr_comm_transport failed")
+    return tp
+
+
+def comm_library_path() -> str:
+    """File name of the RCCL library the loader bound (wr_comm_library_path)."""
+    buf = C.create_string_buffer(1024)
+    rc = load_library().wr_comm_library_path(buf, len(buf))
+    if rc != WR_OK:
+        raise WrError(rc, "wr_comm_library_path failed (is librccl.so.1 loadable?)")
+    return buf.value.decode()
 
 
 class Glb:

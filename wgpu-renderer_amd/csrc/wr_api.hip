@@ -69,6 +69,11 @@ constexpr size_t kStaticNoisePoolEntries = (size_t)1 << 20;
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 constexpr int kMaxScratchDevices = 64;
 static unsigned char* g_scratch_ptr[kMaxScratchDevices];
+// Every static frame on a device uses that device's one array, from whatever context and host
+// thread it comes: g_static_done[device] is recorded behind each of them and the next one waits
+// for it on the device before it touches the array (submission itself is under the mutex).
+static hipEvent_t g_static_done[kMaxScratchDevices];
+static bool g_static_recorded[kMaxScratchDevices];
 static std::mutex g_scratch_mutex;
 
 namespace {
@@ -186,9 +191,10 @@ struct WrContext {
     unsigned long long* d_counters = nullptr;
     // Per set of frame buffers four words: [0] error bits, [1] geometry bin items, [2] shadow bin
     // items, [3] fog (unused).  A set's words belong to the frames rendered on that set, so an
-    // overflow names its frame.
+    // overflow names its frame.  One more group of four, after the sets', is wr_render_frame_static's.
     uint32_t* d_err = nullptr;
     uint64_t frames_submitted = 0;
+    uint64_t static_frames_submitted = 0;
     // The library has queued work of its own on `stream` (counter reset, bin pack / gather, the
     // static frame's clears) since the last frame forked from it.
     bool stream_has_work = true;
@@ -362,8 +368,8 @@ int alloc_frame_scene(WrContext* ctx, Arena& ar, FrameRes* f) {
     const uint32_t nvg = ctx->dev[WR_MODEL_GEOMETRY].nv, ntg = ctx->dev[WR_MODEL_GEOMETRY].ntris;
     const uint32_t ntl = ctx->dev[WR_MODEL_LIGHT_MARKER].ntris, ntf = ctx->dev[WR_MODEL_FOG_VOLUME].ntris;
     const size_t nvs = std::max<uint32_t>(nvg, 1);
-    // (a frame carved from the static buffer is not one of the context's sets: it reports on set 0)
-    const ptrdiff_t set = (f >= &ctx->fr[0] && f < &ctx->fr[WrContext::kMaxFrames]) ? f - &ctx->fr[0] : 0;
+    // (a frame carved from the static buffer is not one of the context's sets: it has error words of its own)
+    const ptrdiff_t set = (f >= &ctx->fr[0] && f < &ctx->fr[WrContext::kMaxFrames]) ? f - &ctx->fr[0] : WrContext::kMaxFrames;
     uint32_t* const err = ctx->d_err + 4 * set;
     WR_HIP(arena_take(ar, f->vout.clip, sizeof(float4) * nvs));
     WR_HIP(arena_take(ar, f->vout.v0, sizeof(float4) * nvs));
@@ -1076,6 +1082,7 @@ int wr_create(const WrConfig* config, WrContext** out_ctx) {
         if (!g_scratch_ptr[config->device]) {
             void* p = nullptr;
             if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return WR_ERR_DEVICE;
+            if (hipEventCreateWithFlags(&g_static_done[config->device], hipEventDisableTiming) != hipSuccess) return WR_ERR_DEVICE;
             g_scratch_ptr[config->device] = static_cast<unsigned char*>(p);
         }
     }
@@ -1114,8 +1121,8 @@ int wr_create(const WrConfig* config, WrContext** out_ctx) {
         WR_HIP(hipMemcpy(ctx->d_tables, tables, sizeof(tables), hipMemcpyHostToDevice));
         WR_HIP(hipMalloc(&ctx->d_counters, 8 * sizeof(unsigned long long)));
         WR_HIP(hipMemset(ctx->d_counters, 0, 8 * sizeof(unsigned long long)));
-        WR_HIP(hipMalloc(&ctx->d_err, 4 * WrContext::kMaxFrames * sizeof(uint32_t)));
-        WR_HIP(hipMemset(ctx->d_err, 0, 4 * WrContext::kMaxFrames * sizeof(uint32_t)));
+        WR_HIP(hipMalloc(&ctx->d_err, 4 * (WrContext::kMaxFrames + 1) * sizeof(uint32_t)));
+        WR_HIP(hipMemset(ctx->d_err, 0, 4 * (WrContext::kMaxFrames + 1) * sizeof(uint32_t)));
         size_t ns = shadow_buffer_floats((int)S);  // faces, then the depth range of their 8x8 tiles
         for (int k = 0; k < ctx->nfr; ++k) {
             FrameRes* f = &ctx->fr[k];
@@ -1292,6 +1299,11 @@ int wr_render_frame_static(WrContext* ctx, const WrCameraUniform* camera, const 
     ar.cap = kStaticScratchBytes;
     if ((rc = carve_static_frame(ctx, ar, &sf)) != WR_OK) return rc;
     sf.d_color = static_cast<uint32_t*>(device_color);
+    // One static frame at a time per device, whichever context or host thread it comes from: the
+    // array is touched only after the static frame before it has finished on the device.
+    std::lock_guard<std::mutex> static_lock(g_scratch_mutex);
+    const int dev = ctx->cfg.device;
+    if (g_static_recorded[dev]) WR_HIP(hipStreamWaitEvent(ctx->stream, g_static_done[dev], 0));
     // The buffer keeps what the last call left: clear what a frame reads before writing it.
     const size_t npx = (size_t)ctx->W * ctx->H;
     WR_HIP(hipMemsetAsync(sf.blend.rp_slot, 0, npx * 4, ctx->stream));
@@ -1305,7 +1317,10 @@ int wr_render_frame_static(WrContext* ctx, const WrCameraUniform* camera, const 
     if ((rc = frame_stages(ctx, &sf, fc, passes, true)) != WR_OK) return rc;
     WR_HIP(hipEventRecord(sf.ev_done, sf.cur_ms));
     ctx->fr[0].submitted = true;
+    ++ctx->static_frames_submitted;
     WR_HIP(hipStreamWaitEvent(ctx->stream, sf.ev_done, 0));
+    WR_HIP(hipEventRecord(g_static_done[dev], ctx->stream));
+    g_static_recorded[dev] = true;
     ctx->stream_has_work = true;  // (the next frame must not touch the shared streams' buffers early)
     return WR_OK;
 }
@@ -1339,10 +1354,17 @@ int wr_sync(WrContext* ctx) {
         int rcs = sync_all(ctx);
         if (rcs != WR_OK) return rcs;
     }
-    uint32_t e[4 * WrContext::kMaxFrames] = {0};
+    uint32_t e[4 * (WrContext::kMaxFrames + 1)] = {0};
     WR_HIP(hipMemcpy(e, ctx->d_err, sizeof(e), hipMemcpyDeviceToHost));
     ctx->stats.geometry_bin_items = e[4 * ctx->cur + 1];
     ctx->stats.shadow_bin_items = e[4 * ctx->cur + 2];
+    if (const uint32_t es = e[4 * WrContext::kMaxFrames]) {
+        WR_HIP(hipMemset(ctx->d_err + 4 * WrContext::kMaxFrames, 0, sizeof(uint32_t)));
+        char msg[256];
+        snprintf(msg, sizeof(msg), "%s capacity exceeded by a wr_render_frame_static call of this context (the latest was number %llu) since the last wr_sync",
+                 (es & kErrClipOverflow) ? "clipped-triangle record" : "bin item", (unsigned long long)ctx->static_frames_submitted);
+        return fail(ctx, WR_ERR_CAPACITY, msg);
+    }
     // the earliest frame that overflowed a list
     int bad = -1;
     for (int k = 0; k < ctx->nfr; ++k)
@@ -1437,26 +1459,44 @@ int wr_gather_bins_via(WrContext* ctx, const WrTransport* tp, uint32_t root) {
     ctx->stream_has_work = true;
     auto check = [&](int rc, const char* what) { return rc == 0 ? WR_OK : fail(ctx, WR_ERR_DEVICE, std::string("bin gather: ") + what + " failed"); };
     int rc;
+    // Once a group is open it is closed whatever happens inside it (an open ncclGroupStart would
+    // defer every later collective of the calling thread): the first failure is remembered,
+    // group_end is called, then the failure is returned.
     if (rank != root) {
         if (owned)
             hipLaunchKernelGGL(k_pack_bins, dim3(owned), dim3(256), 0, ctx->stream, f->d_color, ctx->d_gather_send, ctx->W, ctx->H, bx, nb,
                                (int)rank, (int)world, 1);
         WR_HIP(hipGetLastError());
         if (tp->group_start && (rc = check(tp->group_start(tp->user), "group start")) != WR_OK) return rc;
-        if (owned && (rc = check(tp->send(tp->user, ctx->d_gather_send, owned * bin_bytes, (int)root, ctx->stream), "send")) != WR_OK) return rc;
-        if (tp->group_end && (rc = check(tp->group_end(tp->user), "group end")) != WR_OK) return rc;
-        return WR_OK;
+        int first = WR_OK;
+        if (owned) first = check(tp->send(tp->user, ctx->d_gather_send, owned * bin_bytes, (int)root, ctx->stream), "send");
+        if (tp->group_end) {
+            const std::string kept = ctx->err;
+            rc = check(tp->group_end(tp->user), "group end");
+            if (first != WR_OK) ctx->err = kept;
+            else first = rc;
+        }
+        return first;
     }
     if (tp->group_start && (rc = check(tp->group_start(tp->user), "group start")) != WR_OK) return rc;
-    for (uint32_t r = 0; r < world; ++r) {
-        if (r == root) continue;
-        uint32_t owned_r = 0;
-        wr_gather_layout((uint32_t)ctx->W, (uint32_t)ctx->H, world, r, &owned_r, nullptr);
-        if (!owned_r) continue;
-        void* dst = reinterpret_cast<uint8_t*>(ctx->d_gather_recv) + (size_t)r * slot * bin_bytes;
-        if ((rc = check(tp->recv(tp->user, dst, owned_r * bin_bytes, (int)r, ctx->stream), "receive")) != WR_OK) return rc;
+    {
+        int first = WR_OK;
+        for (uint32_t r = 0; r < world && first == WR_OK; ++r) {
+            if (r == root) continue;
+            uint32_t owned_r = 0;
+            wr_gather_layout((uint32_t)ctx->W, (uint32_t)ctx->H, world, r, &owned_r, nullptr);
+            if (!owned_r) continue;
+            void* dst = reinterpret_cast<uint8_t*>(ctx->d_gather_recv) + (size_t)r * slot * bin_bytes;
+            first = check(tp->recv(tp->user, dst, owned_r * bin_bytes, (int)r, ctx->stream), "receive");
+        }
+        if (tp->group_end) {
+            const std::string kept = ctx->err;
+            rc = check(tp->group_end(tp->user), "group end");
+            if (first != WR_OK) ctx->err = kept;
+            else first = rc;
+        }
+        if (first != WR_OK) return first;
     }
-    if (tp->group_end && (rc = check(tp->group_end(tp->user), "group end")) != WR_OK) return rc;
     hipLaunchKernelGGL(k_scatter_gathered, dim3((uint32_t)nb), dim3(256), 0, ctx->stream, f->d_color, ctx->d_gather_recv, ctx->W, ctx->H, bx,
                        nb, (int)world, (int)root, (int)slot);
     WR_HIP(hipGetLastError());
@@ -1513,7 +1553,9 @@ int rccl_recv(void* comm, void* buf, size_t bytes, int peer, void* stream) {
 int wr_gather_bins(WrContext* ctx, void* nccl_comm, uint32_t root) {
     if (!ctx || !nccl_comm) return fail(ctx, WR_ERR_INVALID_ARGUMENT, "null communicator");
     if (!rccl().ok) return fail(ctx, WR_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded");
-    WrTransport tp{nccl_comm, rccl_group_start, rccl_send, rccl_recv, rccl_group_end};
+    WrTransport tp;
+    const int rc = wr_comm_transport(nccl_comm, &tp);
+    if (rc != WR_OK) return fail(ctx, rc, "no RCCL transport");
     return wr_gather_bins_via(ctx, &tp, root);
 }
 int wr_comm_unique_id(uint8_t id[128]) {
@@ -1534,6 +1576,22 @@ int wr_comm_destroy(void* comm) {
     if (!comm) return WR_OK;
     if (!rccl().ok) return WR_ERR_UNSUPPORTED;
     return rccl().CommDestroy(comm) == 0 ? WR_OK : WR_ERR_DEVICE;
+}
+int wr_comm_transport(void* comm, WrTransport* out) {
+    if (!comm || !out) return WR_ERR_INVALID_ARGUMENT;
+    if (!rccl().ok) return WR_ERR_UNSUPPORTED;
+    *out = WrTransport{comm, rccl_group_start, rccl_send, rccl_recv, rccl_group_end};
+    return WR_OK;
+}
+int wr_comm_library_path(char* path, size_t cap) {
+    if (!path || cap == 0) return WR_ERR_INVALID_ARGUMENT;
+    path[0] = 0;
+    if (!rccl().ok) return WR_ERR_UNSUPPORTED;
+    Dl_info info;
+    memset(&info, 0, sizeof(info));
+    if (!dladdr(reinterpret_cast<void*>(rccl().Send), &info) || !info.dli_fname) return WR_ERR_DEVICE;
+    snprintf(path, cap, "%s", info.dli_fname);
+    return WR_OK;
 }
 
 int wr_set_profiling(WrContext* ctx, int enabled) {
