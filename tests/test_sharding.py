@@ -168,3 +168,64 @@ def test_gloo_gather_to_root_with_the_c_layout(world, root):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(results) == [(r, True) for r in range(world)]
+
+
+# ---------------------------------------------------------------- bench.py: starting N ranks
+def _bench(*argv, env=None):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], capture_output=True, text=True, env=e, timeout=120)
+
+
+def test_bench_starts_its_own_ranks_when_asked_for_more_than_one_gpu():
+    """`python bench.py --gpus N` without WORLD_SIZE is the parent of N ranks: the command it
+    would start is torch.distributed.run with one rank per GPU on 127.0.0.1, with the caller's
+    arguments passed on; with fewer devices than ranks it refuses (here: none) before starting
+    anything."""
+    import json
+    p = _bench("--gpus", "4", "--steps", "7", "--warmup", "2", "--print-launch")
+    assert p.returncode == 0, p.stderr
+    cmd = json.loads(p.stdout)["launch"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    script = cmd.index(next(c for c in cmd if c.endswith("bench.py")))
+    assert cmd[script + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    p = _bench("--gpus", "2", "--steps", "3")
+    assert p.returncode == 2 and "not starting" in p.stderr and p.stdout == ""
+
+
+def _ranks_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import bench
+    r = bench.Ranks()
+    try:
+        r.barrier()
+        got = (r.rank, r.world, r.max_time(1.0 + rank), r.from_root(b"id-%d" % rank if rank == 0 else None))
+        q.put(got)
+    finally:
+        r.close()
+
+
+def test_bench_ranks_talk_over_gloo():
+    """The control plane of a multi-rank bench run (barrier, slowest rank's time, the
+    communicator id from rank 0) with world size 2 on CPU."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ranks_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got == [(0, 2, 2.0, b"id-0"), (1, 2, 2.0, b"id-0")]
