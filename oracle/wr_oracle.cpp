@@ -66,6 +66,12 @@
 //  R16 proj*view is one mat4*mat4 product (columns by R1) done once per frame.
 //
 // Build: make -C oracle   (g++ -O2 -ffp-contract=off -mfma)
+//
+// Alternatives of the rules that no second source checks (R1 inside rand, R3, R4, R12, R13's
+// tie, R15's rounding) can be compiled in, one macro each (WRO_ALT_*), to measure how far a
+// driver that decides differently would move the picture.  scripts/rule_sensitivity.py builds
+// those variants into oracle/_variants/ and records the distances; libwr_oracle.so itself is
+// always built without any of them, and no rule changes because of what they show.
 
 #include <cmath>
 #include <cstdint>
@@ -96,7 +102,11 @@ inline V3 operator/(V3 a, V3 b) { return V3{a.x / b.x, a.y / b.y, a.z / b.z}; }
 inline float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }   // R1
 inline float length3(V3 a) { return sqrtf(dot3(a, a)); }                       // R2
 inline V3 normalize3(V3 a) { float inv = 1.0f / sqrtf(dot3(a, a)); return a * inv; }
+#ifdef WRO_ALT_R3_MIX_ONE_MUL
+inline float mixf(float a, float b, float t) { return a + t * (b - a); }          // R3 alternative: the flrp lowering
+#else
 inline float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }  // R3
+#endif
 inline float saturatef(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 
 inline V4 mul(const M4& m, V4 v) {  // R1
@@ -127,6 +137,13 @@ inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
 // R4: single-precision Cephes sine (the scheme of sse_mathfun's sin_ps, which Mesa's gallivm
 // lowers fsin to), fused multiply-adds in the reduction and the Horner steps.
+#ifdef WRO_ALT_R4_UNFUSED_SINE
+// R4 alternative: the same scheme with every multiply and add rounded on its own (sse_mathfun
+// as written, without the fused forms a compiler may pick).
+inline float o_fma(float a, float b, float c) { return a * b + c; }
+#else
+inline float o_fma(float a, float b, float c) { return fmaf(a, b, c); }
+#endif
 float o_sin(float x) {
     uint32_t sign = f2u(x) & 0x80000000u;
     float ax = fabsf(x);
@@ -137,24 +154,24 @@ float o_sin(float x) {
     y = (float)j;
     sign ^= ((uint32_t)(j & 4)) << 29;
     bool sin_poly = (j & 2) == 0;
-    float r = fmaf(y, -0.78515625f, ax);
-    r = fmaf(y, -2.4187564849853515625e-4f, r);
-    r = fmaf(y, -3.77489497744594108e-8f, r);
+    float r = o_fma(y, -0.78515625f, ax);
+    r = o_fma(y, -2.4187564849853515625e-4f, r);
+    r = o_fma(y, -3.77489497744594108e-8f, r);
     float z = r * r;
     float res;
     if (sin_poly) {
         float p = -1.9515295891e-4f;
-        p = fmaf(p, z, 8.3321608736e-3f);
-        p = fmaf(p, z, -1.6666654611e-1f);
+        p = o_fma(p, z, 8.3321608736e-3f);
+        p = o_fma(p, z, -1.6666654611e-1f);
         p = p * z;
-        res = fmaf(p, r, r);
+        res = o_fma(p, r, r);
     } else {
         float p = 2.443315711809948e-5f;
-        p = fmaf(p, z, -1.388731625493765e-3f);
-        p = fmaf(p, z, 4.166664568298827e-2f);
+        p = o_fma(p, z, -1.388731625493765e-3f);
+        p = o_fma(p, z, 4.166664568298827e-2f);
         p = p * z;
         p = p * z;
-        p = fmaf(z, -0.5f, p);
+        p = o_fma(z, -0.5f, p);
         res = p + 1.0f;
     }
     return u2f(f2u(res) ^ sign);
@@ -172,7 +189,12 @@ float o_hash_of_dot(float d) {
     float fr = s - floorf(s);
     return fr * 2.0f - 1.0f;
 }
+#ifdef WRO_ALT_R1_FUSED_DOT
+// R1 alternative inside rand: the dot product as a chain of fused multiply-adds
+float o_rand(V3 p) { return o_hash_of_dot(fmaf(p.z, 412.12f, fmaf(p.x, 12.345f, p.y * 67.89f))); }
+#else
 float o_rand(V3 p) { return o_hash_of_dot(dot3(p, v3(12.345f, 67.89f, 412.12f))); }
+#endif
 inline float smooth01(float v) {  // R3, smoothstep(0,1,v)
     float t = fminf(fmaxf(v, 0.0f), 1.0f);
     return (t * t) * (3.0f - 2.0f * t);
@@ -229,7 +251,11 @@ struct SrgbTables {
         for (int c = 0; c < 256; ++c) {
             decode[c] = (float)to_linear((double)c / 255.0);
             unorm[c] = (float)c / 255.0f;
+#ifdef WRO_ALT_R15_TRUNCATE
+            thresh[c] = (float)to_linear((double)c / 255.0);  // R15 alternative: codes round down
+#else
             thresh[c] = c == 0 ? 0.0f : (float)to_linear(((double)c - 0.5) / 255.0);
+#endif
         }
     }
     static double to_linear(double s) {
@@ -251,7 +277,11 @@ uint8_t srgb_encode(float x) {
 uint8_t unorm_encode(float a) {
     if (!(a > 0.0f)) return 0;
     if (a >= 1.0f) return 255;
+#ifdef WRO_ALT_R15_TRUNCATE
+    return (uint8_t)(int)(a * 255.0f);
+#else
     return (uint8_t)(int)(a * 255.0f + 0.5f);
+#endif
 }
 
 // ------------------------------------------------------------------------- scene
@@ -493,7 +523,11 @@ inline V4 lerp4(V4 a, V4 b, float f) { return V4{lerpf(a.x, b.x, f), lerpf(a.y, 
 V4 sample_material(const Texture& t, V2 uv, V2 ddx, V2 ddy) {
     float W = (float)t.w, H = (float)t.h;
     float rho = fmaxf(fmaxf(fabsf(ddx.x), fabsf(ddy.x)) * W, fmaxf(fabsf(ddx.y), fabsf(ddy.y)) * H);
+#ifdef WRO_ALT_R13_TIE_MINIFIES
+    if (rho < 1.0f) {  // R13 alternative: lambda = 0 takes the minification filter
+#else
     if (rho <= 1.0f) {
+#endif
         float x = guard_coord(uv.x * W - 0.5f), y = guard_coord(uv.y * H - 0.5f);
         float x0 = floorf(x), y0 = floorf(y);
         float fx = x - x0, fy = y - y0;
@@ -881,6 +915,18 @@ void render(Oracle& o, const WrCameraUniform* cam, const WrLightUniform* light, 
                     V2 uv{ip(B, a0.uv.x, a1.uv.x, a2.uv.x), ip(B, a0.uv.y, a1.uv.y, a2.uv.y)};
                     // R12 quad derivatives
                     int qx = px & ~1, qy = py & ~1;
+#ifdef WRO_ALT_R12_FINE_DERIVATIVES
+                    // R12 alternative: ddx along the fragment's own row, ddy along its own column
+                    V2 q[4];
+                    const int qp[4][2] = {{qx, py}, {qx + 1, py}, {px, qy}, {px, qy + 1}};
+                    for (int k = 0; k < 4; ++k) {
+                        int64_t Eq[3]; float Bq[3];
+                        edge_values(st, qp[k][0], qp[k][1], Eq);
+                        frag_bary(st, Eq, Bq);
+                        q[k] = V2{ip(Bq, a0.uv.x, a1.uv.x, a2.uv.x), ip(Bq, a0.uv.y, a1.uv.y, a2.uv.y)};
+                    }
+                    V2 ddx{q[1].x - q[0].x, q[1].y - q[0].y}, ddy{q[3].x - q[2].x, q[3].y - q[2].y};
+#else
                     V2 q[3];
                     const int qo[3][2] = {{0, 0}, {1, 0}, {0, 1}};
                     for (int k = 0; k < 3; ++k) {
@@ -890,6 +936,7 @@ void render(Oracle& o, const WrCameraUniform* cam, const WrLightUniform* light, 
                         q[k] = V2{ip(Bq, a0.uv.x, a1.uv.x, a2.uv.x), ip(Bq, a0.uv.y, a1.uv.y, a2.uv.y)};
                     }
                     V2 ddx{q[1].x - q[0].x, q[1].y - q[0].y}, ddy{q[2].x - q[0].x, q[2].y - q[0].y};
+#endif
                     V3 tpos = v3(ip(B, a0.tpos.x, a1.tpos.x, a2.tpos.x), ip(B, a0.tpos.y, a1.tpos.y, a2.tpos.y), ip(B, a0.tpos.z, a1.tpos.z, a2.tpos.z));
                     V3 tlight = v3(ip(B, a0.tlight.x, a1.tlight.x, a2.tlight.x), ip(B, a0.tlight.y, a1.tlight.y, a2.tlight.y), ip(B, a0.tlight.z, a1.tlight.z, a2.tlight.z));
                     V3 tview = v3(ip(B, a0.tview.x, a1.tview.x, a2.tview.x), ip(B, a0.tview.y, a1.tview.y, a2.tview.y), ip(B, a0.tview.z, a1.tview.z, a2.tview.z));

@@ -22,46 +22,52 @@ def build():
     subprocess.run(["make", "-C", ORACLE_DIR, "-s"], check=True)
 
 
+def typed(path: str) -> C.CDLL:
+    """Loads a build of the oracle (libwr_oracle.so, or one of the rule-alternative builds of
+    scripts/rule_sensitivity.py) and types its entry points."""
+    L = C.CDLL(path)
+    P = C.c_void_p
+    L.wro_create.restype = P
+    L.wro_create.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+    L.wro_destroy.argtypes = [P]
+    L.wro_add_texture.restype = C.c_uint32
+    L.wro_add_texture.argtypes = [P, P, C.c_uint32, C.c_uint32, C.c_int]
+    L.wro_add_material.restype = C.c_uint32
+    L.wro_add_material.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float]
+    L.wro_add_mesh.argtypes = [P, C.c_uint32, P, C.c_uint32, P, C.c_uint32, C.c_uint32]
+    L.wro_set_instance.argtypes = [P, C.c_uint32, C.POINTER(abi.InstanceRaw)]
+    L.wro_render.restype = C.c_int
+    L.wro_render.argtypes = [P, C.POINTER(abi.CameraUniform), C.POINTER(abi.LightUniform), C.POINTER(abi.GlobalUniforms), C.c_uint32, C.c_int]
+    for n, t in (("wro_color", C.c_uint8), ("wro_depth", C.c_float), ("wro_visibility", C.c_uint32), ("wro_shadow", C.c_float)):
+        getattr(L, n).restype = C.POINTER(t)
+        getattr(L, n).argtypes = [P]
+    L.wro_counters.argtypes = [P, C.POINTER(C.c_uint64)]
+    L.wro_sin.restype = C.c_float
+    L.wro_sin.argtypes = [C.c_float]
+    for n in ("wro_rand", "wro_value_noise", "wro_fbm"):
+        getattr(L, n).restype = C.c_float
+        getattr(L, n).argtypes = [C.POINTER(C.c_float)]
+    L.wro_fog_noise.restype = C.c_float
+    L.wro_fog_noise.argtypes = [C.POINTER(C.c_float), C.c_float]
+    L.wro_depth_to_linear.restype = C.c_float
+    L.wro_depth_to_linear.argtypes = [C.c_float, C.c_float, C.c_float]
+    L.wro_srgb_encode.restype = C.c_uint8
+    L.wro_srgb_encode.argtypes = [C.c_float]
+    L.wro_srgb_decode.restype = C.c_float
+    L.wro_srgb_decode.argtypes = [C.c_uint8]
+    L.wro_brdf.argtypes = [C.POINTER(C.c_float)] * 5 + [C.c_float, C.c_float, C.POINTER(C.c_float)]
+    L.wro_ambient.argtypes = [C.POINTER(C.c_float), C.c_float, C.c_float, C.POINTER(C.c_float)]
+    L.wro_setup_triangle.restype = C.c_int
+    L.wro_setup_triangle.argtypes = [C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), C.c_int]
+    return L
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
         if not os.path.exists(LIB):
             build()
-        L = C.CDLL(LIB)
-        P = C.c_void_p
-        L.wro_create.restype = P
-        L.wro_create.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
-        L.wro_destroy.argtypes = [P]
-        L.wro_add_texture.restype = C.c_uint32
-        L.wro_add_texture.argtypes = [P, P, C.c_uint32, C.c_uint32, C.c_int]
-        L.wro_add_material.restype = C.c_uint32
-        L.wro_add_material.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float]
-        L.wro_add_mesh.argtypes = [P, C.c_uint32, P, C.c_uint32, P, C.c_uint32, C.c_uint32]
-        L.wro_set_instance.argtypes = [P, C.c_uint32, C.POINTER(abi.InstanceRaw)]
-        L.wro_render.restype = C.c_int
-        L.wro_render.argtypes = [P, C.POINTER(abi.CameraUniform), C.POINTER(abi.LightUniform), C.POINTER(abi.GlobalUniforms), C.c_uint32, C.c_int]
-        for n, t in (("wro_color", C.c_uint8), ("wro_depth", C.c_float), ("wro_visibility", C.c_uint32), ("wro_shadow", C.c_float)):
-            getattr(L, n).restype = C.POINTER(t)
-            getattr(L, n).argtypes = [P]
-        L.wro_counters.argtypes = [P, C.POINTER(C.c_uint64)]
-        L.wro_sin.restype = C.c_float
-        L.wro_sin.argtypes = [C.c_float]
-        for n in ("wro_rand", "wro_value_noise", "wro_fbm"):
-            getattr(L, n).restype = C.c_float
-            getattr(L, n).argtypes = [C.POINTER(C.c_float)]
-        L.wro_fog_noise.restype = C.c_float
-        L.wro_fog_noise.argtypes = [C.POINTER(C.c_float), C.c_float]
-        L.wro_depth_to_linear.restype = C.c_float
-        L.wro_depth_to_linear.argtypes = [C.c_float, C.c_float, C.c_float]
-        L.wro_srgb_encode.restype = C.c_uint8
-        L.wro_srgb_encode.argtypes = [C.c_float]
-        L.wro_srgb_decode.restype = C.c_float
-        L.wro_srgb_decode.argtypes = [C.c_uint8]
-        L.wro_brdf.argtypes = [C.POINTER(C.c_float)] * 5 + [C.c_float, C.c_float, C.POINTER(C.c_float)]
-        L.wro_ambient.argtypes = [C.POINTER(C.c_float), C.c_float, C.c_float, C.POINTER(C.c_float)]
-        L.wro_setup_triangle.restype = C.c_int
-        L.wro_setup_triangle.argtypes = [C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), C.c_int]
-        _lib = L
+        _lib = typed(LIB)
     return _lib
 
 
@@ -72,8 +78,8 @@ def f3(v):
 class Oracle:
     """Same call sequence as abi.Renderer, executed by the CPU restatement."""
 
-    def __init__(self, width, height, shadow_map_size=2048):
-        self.L = lib()
+    def __init__(self, width, height, shadow_map_size=2048, library=None):
+        self.L = library if library is not None else lib()
         self.h = self.L.wro_create(width, height, shadow_map_size)
         self.width, self.height, self.shadow_map_size = width, height, shadow_map_size
 
