@@ -25,3 +25,13 @@ for kind, name, n in ((0, "view", st.fog_noise_evals_view), (1, "light", st.fog_
     print(f"== {name}: per level, share of the kernel's evaluations that run the octave (table / direct)")
     for l in range(16):
         print(f"  fbm{l // 8 + 1} octave {l % 8}: table {a[kind, l, 0] / max(n, 1):6.3f}  direct {a[kind, l, 1] / max(n, 1):6.3f}")
+b = np.zeros(2 * 16 * 6, np.uint64)
+lib.wr_dev_read(r.h, 12, b.ctypes.data, b.nbytes)
+b = b.reshape(2, 16, 6)
+for kind, name, n in ((0, "view", st.fog_noise_evals_view), (1, "light", st.fog_noise_evals_light)):
+    print(f"== {name}: directly evaluated octaves per evaluation, by the lattice points their wavefront's direct lanes span (<=64 <=128 <=256 <=512 <=1024 more)")
+    for l in range(16):
+        if b[kind, l].sum():
+            print(f"  fbm{l // 8 + 1} octave {l % 8}: " + "  ".join(f"{x / max(n, 1):6.3f}" for x in b[kind, l]))
+    tot = b[kind].sum(axis=0) / max(n, 1)
+    print("  all levels:     " + "  ".join(f"{x:6.3f}" for x in tot))

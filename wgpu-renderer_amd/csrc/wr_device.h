@@ -793,8 +793,26 @@ WR_HD float lattice_hash(float ux, float uy, float uz) {  // rand(u) of noise.wg
 // Developer build: lane counts per noise level, [kernel kind][level][0 = table hit, 1 = direct].
 __device__ unsigned long long g_dbg_levels[2][16][2];
 #endif
+#if defined(WR_DEV)
+// Developer build: directly evaluated octaves (lanes) by the size of the lattice box their
+// wavefront's direct lanes span, [kernel kind][level][bucket: <= 64, 128, 256, 512, 1024, more points].
+__device__ unsigned long long g_dbg_boxes[2][16][6];
+#endif
 #if defined(WR_DEV) && defined(__HIP_DEVICE_COMPILE__)
 #define WR_DBG_LEVEL(level, direct) atomicAdd(&g_dbg_levels[(level) >> 8][(level) & 15][direct], 1ull)
+__device__ inline void wr_dbg_box(int level, float ux, float uy, float uz) {
+    int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-0x7fffffff, -0x7fffffff, -0x7fffffff};
+    const unsigned long long lanes = __ballot(1);
+    for (unsigned long long m = lanes; m; m &= m - 1ull) {
+        const int l = (int)__builtin_ctzll(m);
+        const int c[3] = {__builtin_amdgcn_readlane((int)ux, l), __builtin_amdgcn_readlane((int)uy, l), __builtin_amdgcn_readlane((int)uz, l)};
+        for (int k = 0; k < 3; ++k) { lo[k] = c[k] < lo[k] ? c[k] : lo[k]; hi[k] = c[k] > hi[k] ? c[k] : hi[k]; }
+    }
+    const long long n = (long long)(hi[0] - lo[0] + 2) * (hi[1] - lo[1] + 2) * (hi[2] - lo[2] + 2);
+    const int bucket = n <= 64 ? 0 : n <= 128 ? 1 : n <= 256 ? 2 : n <= 512 ? 3 : n <= 1024 ? 4 : 5;
+    if ((int)__builtin_ctzll(lanes) == (int)(threadIdx.x & 63u))
+        atomicAdd(&g_dbg_boxes[level >> 8][level & 15][bucket], (unsigned long long)__builtin_popcountll(lanes));
+}
 #else
 #define WR_DBG_LEVEL(level, direct) ((void)0)
 #endif
@@ -817,6 +835,9 @@ WR_HD float value_noise_tab(V3 p, const NoiseTable& t) {
     }
 #ifdef WR_DEV
     WR_DBG_LEVEL(t.dbg_level, 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+    wr_dbg_box(t.dbg_level, ux, uy, uz);
+#endif
 #endif
     return value_noise_t<GUARD>(p);
 }
