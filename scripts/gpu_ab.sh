@@ -4,7 +4,7 @@
 mkdir -p gpurun_out
 for v in "$@"; do
   for nf in 4 1; do
-    WR_HIP_LIBRARY=$PWD/build_dev/libwr_$v.so timeout -k 10 120 python bench.py --no-cpu-baseline --skip-march-alone --steps 200 --warmup 20 --frames-in-flight $nf > gpurun_out/ab_${v}_$nf.json 2> gpurun_out/ab_${v}_$nf.err || { echo "FAILED $v $nf"; tail -5 gpurun_out/ab_${v}_$nf.err; exit 1; }
+    WR_HIP_LIBRARY=$PWD/build_dev/libwr_$v.so timeout -k 10 120 python bench.py --no-cpu-baseline --skip-march-alone --no-scale-workloads --steps 200 --warmup 20 --frames-in-flight $nf > gpurun_out/ab_${v}_$nf.json 2> gpurun_out/ab_${v}_$nf.err || { echo "FAILED $v $nf"; tail -5 gpurun_out/ab_${v}_$nf.err; exit 1; }
     python - "$v" "$nf" <<'PY'
 import json,sys
 v,nf=sys.argv[1:3]

@@ -4,7 +4,7 @@
 mkdir -p gpurun_out
 for round in 1 2 3; do
   for v in "$@"; do
-    WR_HIP_LIBRARY=$PWD/build_dev/libwr_$v.so timeout -k 10 120 python bench.py --no-cpu-baseline --skip-march-alone --steps 600 --warmup 50 --frames-in-flight ${NF:-1} > gpurun_out/ab1_${v}.json 2> gpurun_out/ab1_${v}.err || { echo "FAILED $v"; tail -5 gpurun_out/ab1_${v}.err; exit 1; }
+    WR_HIP_LIBRARY=$PWD/build_dev/libwr_$v.so timeout -k 10 120 python bench.py --no-cpu-baseline --skip-march-alone --no-scale-workloads --steps 600 --warmup 50 --frames-in-flight ${NF:-1} > gpurun_out/ab1_${v}.json 2> gpurun_out/ab1_${v}.err || { echo "FAILED $v"; tail -5 gpurun_out/ab1_${v}.err; exit 1; }
     python - "$v" "$round" <<'PY'
 import json,sys
 v,r=sys.argv[1:3]

@@ -4,7 +4,7 @@
 VAR=$1; shift
 mkdir -p gpurun_out
 for v in "$@"; do
-  env $VAR=$v timeout -k 10 120 python bench.py --no-cpu-baseline --skip-march-alone --steps 200 --warmup 20 --frames-in-flight 1 > gpurun_out/env_$v.json 2> gpurun_out/env_$v.err || { echo "FAILED $v"; tail -5 gpurun_out/env_$v.err; exit 1; }
+  env $VAR=$v timeout -k 10 120 python bench.py --no-cpu-baseline --skip-march-alone --no-scale-workloads --steps 200 --warmup 20 --frames-in-flight 1 > gpurun_out/env_$v.json 2> gpurun_out/env_$v.err || { echo "FAILED $v"; tail -5 gpurun_out/env_$v.err; exit 1; }
   python - "$VAR" "$v" <<'PY'
 import json,sys
 var,v=sys.argv[1:3]

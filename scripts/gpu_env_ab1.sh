@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 for round in 1 2 3; do
   for v in "$@"; do
     if [ "$v" = "-" ]; then unset $VAR; else export $VAR=$v; fi
-    timeout -k 10 120 python bench.py --no-cpu-baseline --skip-march-alone --steps 600 --warmup 50 --frames-in-flight ${NF:-1} > gpurun_out/env1_$v.json 2> gpurun_out/env1_$v.err || { echo "FAILED $v"; tail -5 gpurun_out/env1_$v.err; exit 1; }
+    timeout -k 10 120 python bench.py --no-cpu-baseline --skip-march-alone --no-scale-workloads --steps 600 --warmup 50 --frames-in-flight ${NF:-1} > gpurun_out/env1_$v.json 2> gpurun_out/env1_$v.err || { echo "FAILED $v"; tail -5 gpurun_out/env1_$v.err; exit 1; }
     python - "$VAR" "$v" "$round" <<'PY'
 import json,sys
 var,v,r=sys.argv[1:4]

@@ -2,7 +2,7 @@
 # Developer helper (run through gpurun): frames/s against the number of frames in flight.
 mkdir -p gpurun_out
 for nf in "$@"; do
-  timeout -k 10 120 python bench.py --no-cpu-baseline --skip-march-alone --steps 300 --warmup 30 --frames-in-flight $nf > gpurun_out/nf_$nf.json 2> gpurun_out/nf_$nf.err || { echo "FAILED $nf"; tail -5 gpurun_out/nf_$nf.err; exit 1; }
+  timeout -k 10 120 python bench.py --no-cpu-baseline --skip-march-alone --no-scale-workloads --steps 300 --warmup 30 --frames-in-flight $nf > gpurun_out/nf_$nf.json 2> gpurun_out/nf_$nf.err || { echo "FAILED $nf"; tail -5 gpurun_out/nf_$nf.err; exit 1; }
   python - $nf <<'PY'
 import json,sys
 nf=sys.argv[1]

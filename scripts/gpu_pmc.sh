@@ -5,7 +5,7 @@
 TAG=$1; CTRS=$2; shift; shift
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 240 rocprofv3 --pmc $CTRS -d $R/gpurun_out/$TAG --output-format csv -- python3 $R/bench.py --steps 6 --warmup 2 --frames-in-flight 1 --no-cpu-baseline --skip-march-alone "$@" > $R/gpurun_out/$TAG.log 2>&1 || { tail -5 $R/gpurun_out/$TAG.log; exit 1; }
+timeout -s KILL 240 rocprofv3 --pmc $CTRS -d $R/gpurun_out/$TAG --output-format csv -- python3 $R/bench.py --steps 6 --warmup 2 --frames-in-flight 1 --no-cpu-baseline --skip-march-alone --no-scale-workloads "$@" > $R/gpurun_out/$TAG.log 2>&1 || { tail -5 $R/gpurun_out/$TAG.log; exit 1; }
 cd $R
 CSV=$(find gpurun_out/$TAG -name "*counter_collection.csv" | head -1)
 python scripts/pmc_summary.py $CSV > gpurun_out/${TAG}.txt

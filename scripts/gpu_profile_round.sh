@@ -13,14 +13,14 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 trace() {  # name, frames in flight
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_$1 -- python3 $R/bench.py --steps 100 --warmup 5 --frames-in-flight $2 --no-cpu-baseline --skip-march-alone > $O/${TAG}_$1.log 2>&1 || return 1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_$1 -- python3 $R/bench.py --steps 100 --warmup 5 --frames-in-flight $2 --no-cpu-baseline --skip-march-alone --no-scale-workloads > $O/${TAG}_$1.log 2>&1 || return 1
   DB=$(find $O/${TAG}_$1 -name "*.db" | head -1)
   python3 $R/scripts/rocpd_summary.py $DB > $O/${TAG}_$1_stats.txt
   python3 $R/scripts/frame_timeline.py $DB > $O/${TAG}_$1_timeline.txt
   rm -rf $O/${TAG}_$1
 }
 pmc() {  # name, frames in flight, counters
-  timeout -s KILL 240 rocprofv3 --pmc $3 -d $O/${TAG}_$1 --output-format csv -- python3 $R/bench.py --steps 6 --warmup 2 --frames-in-flight $2 --no-cpu-baseline --skip-march-alone > $O/${TAG}_$1.log 2>&1 || return 1
+  timeout -s KILL 240 rocprofv3 --pmc $3 -d $O/${TAG}_$1 --output-format csv -- python3 $R/bench.py --steps 6 --warmup 2 --frames-in-flight $2 --no-cpu-baseline --skip-march-alone --no-scale-workloads > $O/${TAG}_$1.log 2>&1 || return 1
   CSV=$(find $O/${TAG}_$1 -name "*counter_collection.csv" | head -1)
   python3 $R/scripts/pmc_summary.py $CSV > $O/${TAG}_$1.txt
   rm -rf $O/${TAG}_$1

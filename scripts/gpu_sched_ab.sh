@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 for nf in 4 3 2 1; do
   for sc in mono split; do
-    WR_DEBUG_SCHEDULE=$sc timeout -k 10 120 python bench.py --no-cpu-baseline --skip-march-alone --steps 200 --warmup 20 --frames-in-flight $nf > gpurun_out/sched_${sc}_$nf.json 2> gpurun_out/sched_${sc}_$nf.err || { echo "FAILED $sc $nf"; tail -5 gpurun_out/sched_${sc}_$nf.err; exit 1; }
+    WR_DEBUG_SCHEDULE=$sc timeout -k 10 120 python bench.py --no-cpu-baseline --skip-march-alone --no-scale-workloads --steps 200 --warmup 20 --frames-in-flight $nf > gpurun_out/sched_${sc}_$nf.json 2> gpurun_out/sched_${sc}_$nf.err || { echo "FAILED $sc $nf"; tail -5 gpurun_out/sched_${sc}_$nf.err; exit 1; }
     python - $sc $nf <<'PY'
 import json,sys
 sc,nf=sys.argv[1:3]

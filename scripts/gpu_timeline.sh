@@ -4,7 +4,7 @@
 TAG=$1; N=${2:-1}; shift; shift
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG -- python3 $R/bench.py --steps 40 --warmup 5 --frames-in-flight $N --no-cpu-baseline --skip-march-alone "$@" > $R/gpurun_out/$TAG.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG -- python3 $R/bench.py --steps 40 --warmup 5 --frames-in-flight $N --no-cpu-baseline --skip-march-alone --no-scale-workloads "$@" > $R/gpurun_out/$TAG.log 2>&1 || exit 1
 cd $R
 DB=$(find gpurun_out/$TAG -name "*.db" | head -1)
 python scripts/frame_timeline.py $DB > gpurun_out/${TAG}_timeline.txt
