@@ -842,115 +842,6 @@ WR_HD float value_noise_tab(V3 p, const NoiseTable& t) {
     return value_noise_t<GUARD>(p);
 }
 
-// Lattice hashes shared by the lanes of a wavefront.  The hash of a lattice point depends on its
-// integer coordinates alone, and the 64 samples a wavefront evaluates together (an 8x8 pixel tile
-// at one march step) lie within a few units of each other: in the coarser of the octaves that
-// have no per-frame table their eight-corner footprints overlap many times over.  Where the
-// lattice box around all of the wavefront's samples is small (at most kShareMax points), every
-// point's hash is evaluated once, by one lane, into a slab of LDS, and each lane reads its eight
-// corners from there: the same hash_from_dot of the same dot product as the direct evaluation,
-// so the same bits.  Larger boxes (finer octaves, distant tiles) are evaluated directly as before.
-#ifndef WR_WAVE_SHARE
-#define WR_WAVE_SHARE 1
-#endif
-#ifndef WR_WAVE_SHARE_MAX
-#define WR_WAVE_SHARE_MAX 192
-#endif
-constexpr int kShareMax = WR_WAVE_SHARE_MAX;
-constexpr int kShareScratchWords = kShareMax;  // per wavefront
-struct WaveShare {
-    int* scratch;   // LDS, kShareScratchWords ints of this wavefront (nullptr: no sharing)
-};
-// Lattice coordinates of the active lanes' samples in the finest octave's lattice (p * 128,
-// floored: exact, a power of two) and their bounds over the wavefront: floor(p * 2^i) of octave i
-// is that coordinate shifted right by 7 - i (an arithmetic shift floors).
-struct ShareBox {
-    int fx, fy, fz;           // this lane's sample in the level-7 lattice
-    int lo[3], hi[3];         // wave-uniform bounds over the active lanes
-    uint32_t rank, nact;      // this lane's rank among the active lanes, their number
-};
-// The slab is written and read by one wavefront only, and the LDS serves a wavefront's accesses
-// in the order it issued them: all that has to be kept is the order of the instructions.
-__device__ inline void wave_lds_order() {
-#ifdef WR_WAVE_SHARE_FENCE
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#else
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("" ::: "memory");
-#endif
-}
-// Minimum and maximum of three integers over the 64 lanes of a wavefront that is whole (every
-// lane enabled): a butterfly inside each row of sixteen lanes, then the rows' results passed on
-// to the last lane (row broadcasts), one fused DPP instruction per value and step.  The six
-// reductions are interleaved, so that no instruction reads a register written less than three
-// instructions earlier (a DPP operand needs two wait states after a VALU write; the leading
-// s_nop covers the registers' last writes by the code before).
-__device__ inline void wave_box_full(int x, int y, int z, int lo[3], int hi[3]) {
-    int a = x, b = y, c = z, d = x, e = y, f = z;
-#define WR_DPP6(ctrl)                                   \
-    "v_min_i32_dpp %0, %0, %0 " ctrl "\n\t"             \
-    "v_min_i32_dpp %1, %1, %1 " ctrl "\n\t"             \
-    "v_min_i32_dpp %2, %2, %2 " ctrl "\n\t"             \
-    "v_max_i32_dpp %3, %3, %3 " ctrl "\n\t"             \
-    "v_max_i32_dpp %4, %4, %4 " ctrl "\n\t"             \
-    "v_max_i32_dpp %5, %5, %5 " ctrl "\n\t"
-    asm volatile("s_nop 1\n\t"
-                 WR_DPP6("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
-                 WR_DPP6("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
-                 WR_DPP6("row_half_mirror row_mask:0xf bank_mask:0xf")
-                 WR_DPP6("row_mirror row_mask:0xf bank_mask:0xf")
-                 WR_DPP6("row_bcast:15 row_mask:0xa bank_mask:0xf")
-                 WR_DPP6("row_bcast:31 row_mask:0xc bank_mask:0xf")
-                 "s_nop 1"
-                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
-#undef WR_DPP6
-    lo[0] = __builtin_amdgcn_readlane(a, 63); lo[1] = __builtin_amdgcn_readlane(b, 63); lo[2] = __builtin_amdgcn_readlane(c, 63);
-    hi[0] = __builtin_amdgcn_readlane(d, 63); hi[1] = __builtin_amdgcn_readlane(e, 63); hi[2] = __builtin_amdgcn_readlane(f, 63);
-}
-// The caller has made sure that the wavefront is whole.
-__device__ inline ShareBox share_box(V3 p) {
-    ShareBox b;
-    b.fx = (int)floorf(p.x * 128.0f); b.fy = (int)floorf(p.y * 128.0f); b.fz = (int)floorf(p.z * 128.0f);
-    b.nact = 64u;
-    b.rank = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    wave_box_full(b.fx, b.fy, b.fz, b.lo, b.hi);
-    return b;
-}
-// value_noise of octave `sh` levels above the finest (q = p * 2^(7 - sh)) from the shared slab.
-// (lx, nx) ...: the wavefront's lattice box at this octave, n = nx * ny * nz <= kShareMax points.
-template <int GUARD>
-__device__ inline float value_noise_shared(V3 q, const ShareBox& b, int sh, int lx, int ly, int lz, int nx, int ny, int n, float* slab) {
-    const int nxy = nx * ny;
-    // point e of the box = (i, j, k) with e = (k * ny + j) * nx + i; the quotients through
-    // reciprocals: (e + 0.5) / m is at least 0.5 / m away from an integer, far beyond the
-    // reciprocal's error for e < kShareMax
-    const float rxy = __builtin_amdgcn_rcpf((float)nxy), rx = __builtin_amdgcn_rcpf((float)nx);
-    wave_lds_order();  // the slab's readers of the octave before are done
-    for (uint32_t base = 0; base < (uint32_t)n; base += b.nact) {
-        const int e = (int)(base + b.rank);
-        if (e < n) {
-            const int k = (int)(((float)e + 0.5f) * rxy);
-            const int r = e - k * nxy;
-            const int j = (int)(((float)r + 0.5f) * rx);
-            const int i = r - j * nx;
-            // rand(u) of noise.wgsl:3-5 for the integer u, the products and sums of value_noise_t
-            const float d = ((float)(lx + i) * 12.345f + (float)(ly + j) * 67.89f) + (float)(lz + k) * 412.12f;
-            slab[e] = hash_from_dot<GUARD>(d);
-        }
-    }
-    wave_lds_order();
-    const int ix = b.fx >> sh, iy = b.fy >> sh, iz = b.fz >> sh;
-    const float ux = (float)ix, uy = (float)iy, uz = (float)iz;  // = floor(q), exactly
-    const float sx = smooth01(q.x - ux), sy = smooth01(q.y - uy), sz = smooth01(q.z - uz);
-    const float* c = slab + ((iz - lz) * ny + (iy - ly)) * nx + (ix - lx);
-    const float a = c[0], bb = c[1], cc = c[nx], d = c[nx + 1];
-    const float e = c[nxy], f = c[nxy + 1], g = c[nxy + nx], h = c[nxy + nx + 1];
-    return mixf(mixf(mixf(a, bb, sx), mixf(cc, d, sx), sy), mixf(mixf(e, f, sx), mixf(g, h, sx), sy), sz);
-}
-
 // fbm returns saturate(sum); once the partial sum is so far below 0 (or above 1) that the
 // octaves still to come cannot bring it back, the result is known: 0 (or 1), the same bits
 // the full sum would saturate to.  What is still to come after octave i is at most
@@ -993,39 +884,6 @@ WR_HD float fbm_tab_t(V3 p, const NoiseTable* tabs) {
     }
     return saturatef(ret);
 }
-// fbm_tab_t for a wavefront that shares the hashes of the untabled octaves whose lattice box is
-// small.  Octave i's box has about eight times the points of octave i - 1's, so once a box is
-// too large the finer octaves are not asked again.
-template <int GUARD>
-__device__ inline float fbm_share_t(V3 p, const NoiseTable* tabs, const WaveShare& ws) {
-    const ShareBox b = share_box(p);
-    float* slab = reinterpret_cast<float*>(ws.scratch);
-    bool share = true;
-    float weight = 0.5f, ret = 0.0f;
-    V3 q = p;
-    for (int i = 0; i < 8; ++i) {
-        float vn;
-        bool done = false;
-        if (tabs[i].data == nullptr && share) {
-            const int sh = 7 - i;
-            const int lx = b.lo[0] >> sh, ly = b.lo[1] >> sh, lz = b.lo[2] >> sh;
-            const int nx = (b.hi[0] >> sh) - lx + 2, ny = (b.hi[1] >> sh) - ly + 2, nz = (b.hi[2] >> sh) - lz + 2;
-            const int n = nx * ny * nz;
-            if (nx <= kShareMax && ny <= kShareMax && nz <= kShareMax && n <= kShareMax) {
-                vn = value_noise_shared<GUARD>(q, b, sh, lx, ly, lz, nx, ny, n, slab);
-                done = true;
-            } else {
-                share = false;
-            }
-        }
-        if (!done) vn = value_noise_tab<GUARD>(q, tabs[i]);
-        ret += weight * vn;
-        if (i < 7 && fbm_decided(ret, i)) break;
-        q = q * 2.0f;
-        weight *= 0.5f;
-    }
-    return saturatef(ret);
-}
 // noise.wgsl:26-40.  The last octave samples p*128 and every hash argument is at most
 // (|q|+1) * (12.345 + 67.89 + 412.12) (1 + 3*2^-24); for |p| < 16000 that stays below 2^30,
 // the sine's range guard can never fire and an unguarded instantiation is used; for
@@ -1052,16 +910,6 @@ WR_HD float fbm_tab(V3 p, const NoiseTable* tabs) {
     if (tier == kSinInt) return fbm_tab_t<kSinInt>(p, tabs);
     return fbm_t<kSinGuarded>(p);
 }
-// (sharing is built for the fast sine tier, which is every sample of a scene of the reference's
-// size at its times; other samples take the per-lane path)
-__device__ inline float fbm_tab(V3 p, const NoiseTable* tabs, const WaveShare& ws) {
-    const int tier = fbm_sin_tier(p);
-    // (a wavefront that is not whole here, because its lanes differ in tier or came here through a
-    // divergent branch, evaluates lane by lane)
-    if (tier == kSinFast) return (WR_WAVE_SHARE && ws.scratch != nullptr && __ballot(1) == ~0ull) ? fbm_share_t<kSinFast>(p, tabs, ws) : fbm_tab_t<kSinFast>(p, tabs);
-    if (tier == kSinInt) return fbm_tab_t<kSinInt>(p, tabs);
-    return fbm_t<kSinGuarded>(p);
-}
 // fog.wgsl:48-62
 WR_HD float fog_noise(const FrameConsts& fc, V3 pos) {
     V3 p1 = pos * 0.01f;
@@ -1081,37 +929,22 @@ WR_HD float fog_noise_tab(const FrameConsts& fc, const NoiseTables& nt, V3 pos) 
     float n2 = fbm_tab(p2, nt.level + 8);
     return (0.8f * n1 + 0.15f * n2) + 0.05f;
 }
-__device__ inline float fog_noise_tab(const FrameConsts& fc, const NoiseTables& nt, V3 pos, const WaveShare& ws) {
-    V3 p1 = pos * 0.01f;
-    p1.x += fc.drift_xy; p1.y += fc.drift_xy; p1.z += fc.drift_z;
-    float n1 = fbm_tab(p1, nt.level, ws);
-    V3 p2 = pos * 0.05f;
-    p2.x += fc.drift_xy; p2.y += fc.drift_xy; p2.z += fc.drift_z;
-    float n2 = fbm_tab(p2, nt.level + 8, ws);
-    return (0.8f * n1 + 0.15f * n2) + 0.05f;
-}
 // fog.wgsl:64-85.  Returns (density, depth); `evals` counts fog_noise calls.  nt == nullptr
 // evaluates every hash directly.
-template <class NoiseAtPos>
-WR_HD V2 ray_march_with(NoiseAtPos noise_at_pos, V3 origin, V3 dir, float max_depth, int max_steps, float step_size, float fog_density,
-                        uint32_t& evals) {
+WR_HD V2 ray_march(const FrameConsts& fc, const NoiseTables* nt, V3 origin, V3 dir, float max_depth, int max_steps,
+                   float step_size, float fog_density, uint32_t& evals) {
     float density = 0.0f, depth = 0.0f;
     float contribution = fog_density / (float)max_steps;
     for (int i = 0; i < max_steps; ++i) {
         depth += step_size;
         if (depth >= max_depth) break;
         V3 pos = origin + dir * depth;
-        float noise = noise_at_pos(pos);
+        float noise = nt ? fog_noise_tab(fc, *nt, pos) : fog_noise(fc, pos);
         ++evals;
         density += noise * contribution;
         if (density >= 1.0f) { density = 1.0f; break; }
     }
     return V2{density, depth};
-}
-WR_HD V2 ray_march(const FrameConsts& fc, const NoiseTables* nt, V3 origin, V3 dir, float max_depth, int max_steps,
-                   float step_size, float fog_density, uint32_t& evals) {
-    return ray_march_with([&fc, nt](V3 pos) { return nt ? fog_noise_tab(fc, *nt, pos) : fog_noise(fc, pos); }, origin, dir, max_depth, max_steps,
-                          step_size, fog_density, evals);
 }
 // fog.wgsl:118-123
 WR_HD float depth_to_linear(float depth, float zn, float zf) { return (zn * zf) / (zf + depth * (zn - zf)); }
@@ -1212,26 +1045,6 @@ WR_HD V4 fog_march_shade(const FrameConsts& fc, const ShadowMap& sm, const Noise
         // reads: a fog point in shadow does not need it, and it is not run for one.
         LightRay lr = fog_light_ray(fc, fog_position);
         V2 lm = ray_march(fc, nt, lr.origin, lr.dir, lr.max_dist, kFogLightMaxSteps, kFogLightStepSize, kFogLightDensity, evals);
-        occlusion = lm.x;
-    }
-    return fog_shade(fc, fog_position, fog_density, in_light, occlusion);
-}
-
-// The same with the wavefront's lattice hashes shared (the lanes of a wavefront run both marches
-// together; lanes whose march has ended, or whose fog point is in shadow, sit the steps out).
-__device__ inline V4 fog_march_shade(const FrameConsts& fc, const ShadowMap& sm, const NoiseTables& nt, V3 origin, float max_fog_depth,
-                                     uint32_t& evals, const WaveShare& ws) {
-    V3 cam = v3(fc.cam_pos[0], fc.cam_pos[1], fc.cam_pos[2]);
-    V3 direction = normalize3(origin - cam);
-    auto noise = [&fc, &nt, &ws](V3 pos) { return fog_noise_tab(fc, nt, pos, ws); };
-    V2 fm = ray_march_with(noise, origin, direction, max_fog_depth, kFogMaxSteps, kFogStepSize, kFogDensity, evals);
-    float fog_density = fm.x, fog_depth = fm.y;
-    V3 fog_position = origin + direction * fog_depth;
-    float in_light = sample_direct_light<false>(fc, sm, V4{fog_position.x, fog_position.y, fog_position.z, 1.0f});
-    float occlusion = 0.0f;
-    if (in_light > 0.0f) {
-        LightRay lr = fog_light_ray(fc, fog_position);
-        V2 lm = ray_march_with(noise, lr.origin, lr.dir, lr.max_dist, kFogLightMaxSteps, kFogLightStepSize, kFogLightDensity, evals);
         occlusion = lm.x;
     }
     return fog_shade(fc, fog_position, fog_density, in_light, occlusion);

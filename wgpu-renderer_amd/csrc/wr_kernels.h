@@ -1438,22 +1438,13 @@ __device__ inline V3 fog_item_dir(const FrameConsts& fc, V3 origin) {  // fog.wg
 // column of the [step][cap] noise array.
 template <bool COUNT>
 __device__ inline void fog_noise_steps(const FogArgs& a, bool live, V3 origin, V3 dir, float max_depth, float step_size,
-                                       int max_steps, int s0, float* out, unsigned long long* counter, const WaveShare& ws) {
+                                       int max_steps, int s0, float* out, unsigned long long* counter) {
 #pragma unroll 1
     for (int s = s0; s < s0 + kFogStepGroup && s < max_steps; ++s) {
         const float depth = march_step_depth(step_size, s);
         const bool act = live && !(depth >= max_depth);  // the march's exit test, fog.wgsl:70-72
-        const unsigned long long am = __ballot(act);
-        if (!am) break;                                  // depth only grows: no later step is active either
-        // The whole wavefront goes through the noise (its lanes share lattice hashes): a lane
-        // without a sample at this step takes the first sample's position and drops the result.
-        V3 pos = origin + dir * depth;
-        const int src = (int)__builtin_ctzll(am);
-        pos.x = act ? pos.x : u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(pos.x), src));
-        pos.y = act ? pos.y : u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(pos.y), src));
-        pos.z = act ? pos.z : u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(pos.z), src));
-        const float noise = fog_noise_tab(a.fc, a.tables_noise, pos, ws);
-        if (act) out[(size_t)s * a.cap] = noise;
+        if (!__any(act ? 1 : 0)) break;                  // depth only grows: no later step is active either
+        if (act) out[(size_t)s * a.cap] = fog_noise_tab(a.fc, a.tables_noise, origin + dir * depth);
         if (COUNT && act) atomicAdd(counter, 1ull);
     }
 }
@@ -1465,7 +1456,6 @@ __device__ inline void fog_noise_steps(const FogArgs& a, bool live, V3 origin, V
 // once, come after all of them instead of taking wave slots in between.
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_fog_noise_view(FogArgs a) {
-    __shared__ int s_share[4][kShareScratchWords];  // per wavefront: box and slab of the shared lattice hashes
     const uint32_t n = *a.item_count;
     const uint32_t blocks = (n + 255u) / 256u;
     if (blockIdx.x >= blocks * (uint32_t)kFogViewGroups) return;
@@ -1475,9 +1465,8 @@ __global__ __launch_bounds__(256) void k_fog_noise_view(FogArgs a) {
     const bool live = k < n;
     const float4 ray = live ? a.item_ray[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const V3 origin = v3(ray.x, ray.y, ray.z);
-    const WaveShare ws{s_share[threadIdx.x >> 6]};
     fog_noise_steps<COUNT>(a, live, origin, fog_item_dir(a.fc, origin), ray.w, kFogStepSize, kFogMaxSteps,
-                           (int)group * kFogStepGroup, a.noise_view + k, &a.counters[5], ws);
+                           (int)group * kFogStepGroup, a.noise_view + k, &a.counters[5]);
 }
 
 // A workgroup takes kResolveChunks chunks of 256 consecutive items and reserves room in the lit
@@ -1542,7 +1531,6 @@ __global__ __launch_bounds__(256) void k_fog_view_resolve(FogArgs a) {
 
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_fog_noise_light(FogArgs a) {
-    __shared__ int s_share[4][kShareScratchWords];
     const uint32_t n = *a.lit_count;
     const uint32_t blocks = (n + 255u) / 256u;
     if (blockIdx.x >= blocks * (uint32_t)kFogLightGroups) return;
@@ -1555,9 +1543,8 @@ __global__ __launch_bounds__(256) void k_fog_noise_light(FogArgs a) {
     const float4 res = a.item_res[k];
     const V3 origin = v3(ray.x, ray.y, ray.z);
     const LightRay lr = fog_light_ray(a.fc, origin + fog_item_dir(a.fc, origin) * res.y);
-    const WaveShare ws{s_share[threadIdx.x >> 6]};
     fog_noise_steps<COUNT>(a, live, lr.origin, lr.dir, lr.max_dist, kFogLightStepSize, kFogLightMaxSteps,
-                           (int)group * kFogStepGroup, a.noise_light + j, &a.counters[6], ws);
+                           (int)group * kFogStepGroup, a.noise_light + j, &a.counters[6]);
 }
 
 // Blends SrcAlpha / OneMinusSrcAlpha over the finished geometry colour (state.rs:501).
@@ -1598,13 +1585,12 @@ __global__ __launch_bounds__(256) void k_fog_shade_blend(FogArgs a) {
 // fill every slot to the end and suit a frame that has the device to itself.
 template <bool COUNT>
 __global__ __launch_bounds__(64) void k_fog_march(FogArgs a) {
-    __shared__ int s_share[kShareScratchWords];
     const uint32_t k = blockIdx.x * 64u + threadIdx.x;
     if (k >= *a.item_count) return;
     const float4 ray = a.item_ray[k];
     ShadowMap sm{a.shadow, a.fc.S};
     uint32_t evals = 0;
-    V4 src = fog_march_shade(a.fc, sm, a.tables_noise, v3(ray.x, ray.y, ray.z), ray.w, evals, WaveShare{s_share});
+    V4 src = fog_march_shade(a.fc, sm, &a.tables_noise, v3(ray.x, ray.y, ray.z), ray.w, evals);
     if (COUNT) atomicAdd(&a.counters[1], (unsigned long long)evals);
     a.item_res[k] = make_float4(src.x, src.y, src.z, src.w);
 }
