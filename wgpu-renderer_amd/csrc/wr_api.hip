@@ -1794,6 +1794,18 @@ extern "C" int wr_dev_read(WrContext* ctx, int which, void* dst, size_t bytes) {
         if (bytes && hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dbg_levels), bytes) != hipSuccess) return -1;
         return (int)(have / 4);
     }
+    if ((which >> 1) == 8) {
+        have = sizeof(unsigned long long) * 8;
+        if (bytes > have) bytes = have;
+        if (bytes && hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dbg_blocks), bytes) != hipSuccess) return -1;
+        return (int)(have / 4);
+    }
+    if ((which >> 1) == 7) {
+        have = sizeof(unsigned long long) * 3 * 8;
+        if (bytes > have) bytes = have;
+        if (bytes && hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dbg_phase), bytes) != hipSuccess) return -1;
+        return (int)(have / 4);
+    }
     if ((which >> 1) == 6) {
         have = sizeof(unsigned long long) * 2 * 16 * 6;
         if (bytes > have) bytes = have;

@@ -593,6 +593,17 @@ constexpr int raster_lane_area() { return MODE == 2 ? WR_RASTER_LANE_AREA_LAYERS
 // overlap with the kernels of the neighbouring streams.
 #ifdef WR_DEV
 __device__ unsigned long long g_dbg_cycles[3 * 40000];
+// Developer build: wall-clock ticks of thread 0 of every bin's workgroup, summed per raster mode and
+// phase: [0] tile initialisation up to the first barrier, [1] list + record loads and the
+// one-lane-per-triangle path, [2] the wavefront-per-triangle path, [3] write-out, [4] bins, [5] chunks,
+// [6] large triangles.
+__device__ unsigned long long g_dbg_phase[3][8];
+// shadow walk, wavefront path: [0] 8x8 blocks visited, [1] of those, blocks in which no texel got nearer,
+// [2] blocks in which every texel is covered; lane path: [3] triangles, [4] of those, triangles that changed no texel
+__device__ unsigned long long g_dbg_blocks[8];
+#define WR_PHASE(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_dbg_phase[MODE][i], t_ - dbg_tp); dbg_tp = t_; } } while (0)
+#else
+#define WR_PHASE(i) ((void)0)
 #endif
 template <int MODE, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, uint32_t* vis, float* depth,
@@ -608,6 +619,7 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
     const int b = blockIdx.x, layer = blockIdx.y;
 #ifdef WR_DEV
     const unsigned long long dbg_t0 = wall_clock64();
+    unsigned long long dbg_tp = dbg_t0;
 #endif
     if (!bin_owned(b, tile_rank, tile_world)) return;
     if (MODE == kRasterLayers && ls.bin_flag[b] == 0u) return;
@@ -643,6 +655,7 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
     for (uint32_t c0 = 0; c0 < n; c0 += kRasterThreads) {
         if (tid == 0) s_nbig = 0;
         __syncthreads();  // also orders the tile initialisation before the first atomics
+        if (c0 == 0) WR_PHASE(0);
         if (c0 + tid < n && off + c0 + tid < ws.items_cap) {
             const uint32_t ri = ws.bin_items[off + c0 + tid];
             Rec r = load_rec(&recs[ri]);
@@ -674,6 +687,9 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
                 const int32_t dx0 = e.A[0] * 256, dx1 = e.A[1] * 256, dx2 = e.A[2] * 256;
                 const int32_t dy0 = e.B[0] * 256, dy1 = e.B[1] * 256, dy2 = e.B[2] * 256;
                 int32_t r0 = (int32_t)E[0] + e.tlb[0], r1 = (int32_t)E[1] + e.tlb[1], r2 = (int32_t)E[2] + e.tlb[2];
+#ifdef WR_DEV
+                bool dbg_any = false;
+#endif
                 for (int py = y0; py <= y1; ++py) {
                     int32_t b0 = r0, b1 = r1, b2 = r2;
                     for (int px = x0; px <= x1; ++px) {
@@ -681,18 +697,28 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
                             float l1 = (float)(b1 - e.tlb[1]) * r.inv2A, l2 = (float)(b2 - e.tlb[2]) * r.inv2A;
                             float z = (r.z0 + l1 * r.dz1) + l2 * r.dz2;
                             z = fminf(fmaxf(z, 0.0f), 1.0f);
+#ifdef WR_DEV
+                            if (MODE == kRasterShadow) dbg_any = dbg_any || f2u(fminf(fmaxf(z + r.iw0, 0.0f), 1.0f)) < tile32[tile_index(px - ox, py - oy)];
+#endif
                             raster_emit<MODE>(r, z, tile_index(px - ox, py - oy), tile, tile32, ls);
                         }
                         b0 += dx0; b1 += dx1; b2 += dx2;
                     }
                     r0 += dy0; r1 += dy1; r2 += dy2;
                 }
+#ifdef WR_DEV
+                if (MODE == kRasterShadow) { atomicAdd(&g_dbg_blocks[3], 1ull); if (!dbg_any) atomicAdd(&g_dbg_blocks[4], 1ull); }
+#endif
             } else {
                 bigq[atomicAdd(&s_nbig, 1u)] = ri;
             }
         }
         __syncthreads();
+        WR_PHASE(1);
         const uint32_t nbig = s_nbig;
+#ifdef WR_DEV
+        if (threadIdx.x == 0) { atomicAdd(&g_dbg_phase[MODE][5], 1ull); atomicAdd(&g_dbg_phase[MODE][6], (unsigned long long)nbig); }
+#endif
         for (uint32_t q = wave; q < nbig; q += kRasterThreads / 64) {
             // Wave-uniform record.  Step 1: lane (bx, by) classifies 8x8 pixel block (bx, by)
             // of the bin: M[i] is the largest value edge function i (plus its fill-rule
@@ -723,6 +749,9 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
                 const int blk = (int)__builtin_ctzll(todo);
                 todo &= todo - 1ull;
                 int64_t T[3];
+#ifdef WR_DEV
+                bool dbg_changed = false, dbg_cov = false;
+#endif
                 for (int i = 0; i < 3; ++i) {
                     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)Mv[i], blk);
                     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)Mv[i] >> 32), blk);
@@ -740,13 +769,28 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
                     const float l1 = f1 * r.inv2A, l2 = f2 * r.inv2A;
                     float z = (r.z0 + l1 * r.dz1) + l2 * r.dz2;
                     z = fminf(fmaxf(z, 0.0f), 1.0f);
+#ifdef WR_DEV
+                    if (MODE == kRasterShadow) {
+                        const float zb_ = fminf(fmaxf(z + r.iw0, 0.0f), 1.0f);
+                        dbg_changed = f2u(zb_) < tile32[tile_index((blk & 7) * 8 + lx, (blk >> 3) * 8 + ly)];
+                        dbg_cov = true;
+                    }
+#endif
                     raster_emit<MODE>(r, z, tile_index((blk & 7) * 8 + lx, (blk >> 3) * 8 + ly), tile, tile32, ls);
                 }
+#ifdef WR_DEV
+                if (MODE == kRasterShadow) {
+                    const unsigned long long ch = __ballot(dbg_changed), cv = __ballot(dbg_cov);
+                    if (lane == 0) { atomicAdd(&g_dbg_blocks[0], 1ull); if (!ch) atomicAdd(&g_dbg_blocks[1], 1ull); if (cv == ~0ull) atomicAdd(&g_dbg_blocks[2], 1ull); }
+                }
+#endif
             }
         }
         __syncthreads();
+        WR_PHASE(2);
     }
     __syncthreads();
+    if (n == 0) WR_PHASE(0);
     if (MODE == kRasterShadow) {
         // The face's texels, and the depth range of each 8x8 texel tile behind the faces (see
         // ShadowMap): a wavefront holds one row of the bin, eight lanes one row of a tile.  Depths
@@ -780,6 +824,8 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
         }
 #ifdef WR_DEV
         if (threadIdx.x == 0) g_dbg_cycles[MODE * 40000 + (int)gb] = wall_clock64() - dbg_t0;
+        WR_PHASE(3);
+        if (threadIdx.x == 0) atomicAdd(&g_dbg_phase[MODE][4], 1ull);
 #endif
         return;
     }
@@ -799,6 +845,8 @@ __global__ __launch_bounds__(THREADS) void k_raster(RasterWS ws, int W, int H, u
     }
 #ifdef WR_DEV
     if (threadIdx.x == 0) g_dbg_cycles[MODE * 40000 + (int)gb] = wall_clock64() - dbg_t0;
+    WR_PHASE(3);
+    if (threadIdx.x == 0) atomicAdd(&g_dbg_phase[MODE][4], 1ull);
 #endif
 }
 
