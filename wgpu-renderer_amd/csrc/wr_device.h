@@ -143,8 +143,18 @@ WR_HD float wr_sin_t(float x) {
     pc = pc * z;
     pc = fmaf(z, -0.5f, pc);
     pc = pc + 1.0f;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(WR_SIN_SELECT_BY_COMPARE)
+    // bit 0 of the half octant, spread over a word, picks the polynomial bit by bit: a bit-field
+    // extract and a bit select where a test, a compare and a conditional move were (one
+    // instruction less in each of the eight hashes of an octave)
+    uint32_t pick;  // (as assembly: the optimiser turns the plain expression back into the test and compare)
+    asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(pick) : "v"(half_octant));
+    const uint32_t res = (f2u(pc) & pick) | (f2u(ps) & ~pick);
+    return u2f(res ^ ((sign ^ (half_octant << 30)) & 0x80000000u));
+#else
     const float res = (half_octant & 1u) ? pc : ps;
     return u2f(f2u(res) ^ ((sign ^ (half_octant << 30)) & 0x80000000u));
+#endif
 }
 WR_HD float wr_sin(float x) { return wr_sin_t<true>(x); }
 
