@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiles of the current build for profiles/ (run on the GPU box through gpurun):
-#   bash scripts/gpu_profile_round.sh r02
+#   bash scripts/gpu_profile_round.sh r03
 # writes under gpurun_out/: TAG_kernel_stats.txt (default bench command, kernel trace),
 # TAG_one_frame_kernel_stats.txt + TAG_one_frame_timeline.txt (one frame in flight),
 # TAG_pmc_sq_{1,4}.txt, TAG_pmc_fetch_{1,4}.txt, TAG_pmc_write_{1,4}.txt (counter passes with
@@ -8,7 +8,7 @@
 # TAG_counters.json (scripts/make_profile_json.py), which bench.py reads.
 # Every rocprofv3 run has the program directly after "--" and its own time limit; counter
 # passes hold one block's counters each.
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp

@@ -1,7 +1,7 @@
 """Collects the counter summaries scripts/gpu_profile_round.sh left under gpurun_out/ into
 gpurun_out/TAG_counters.json: per fog schedule ("1": one frame in flight, "4": frames
 overlapping) and kernel the mean per dispatch of the VALU wave-instructions, FETCH_SIZE and
-WRITE_SIZE (KB), GRBM_GUI_ACTIVE, plus the hash of the kernel sources the profile was taken on
+WRITE_SIZE (KB), GRBM_GUI_ACTIVE, the kernel's average duration in the kernel trace, plus the hash of the kernel sources the profile was taken on
 (bench.py prints the figures only for a build with the same hash)."""
 import json
 import os
@@ -26,10 +26,22 @@ def table(path):
     return rows
 
 
+def trace_averages(path):
+    """kernel -> average duration (ns) in a rocpd_summary.py table of a kernel trace."""
+    avg = {}
+    if os.path.exists(path):
+        for ln in open(path).read().splitlines()[1:]:
+            parts = ln.split()
+            if len(parts) >= 7:
+                avg[" ".join(parts[:-6]).replace("wr::", "")] = float(parts[-4]) * 1e3
+    return avg
+
+
 def main():
     tag = sys.argv[1]
     out = {"source_hash": source_hash(), "tag": tag, "schedules": {}}
     for n in ("1", "4"):
+        tr = trace_averages(os.path.join(ROOT, "gpurun_out", f"{tag}_{'kernel' if n == '4' else 'one_frame'}_stats.txt"))
         sq = table(os.path.join(ROOT, "gpurun_out", f"{tag}_pmc_sq_{n}.txt"))
         fe = table(os.path.join(ROOT, "gpurun_out", f"{tag}_pmc_fetch_{n}.txt"))
         wr = table(os.path.join(ROOT, "gpurun_out", f"{tag}_pmc_write_{n}.txt"))
@@ -44,6 +56,9 @@ def main():
                 "gui_active_cycles_all_xcds": get("GRBM_GUI_ACTIVE"),
                 "fetch_size_kb": (list(fe.get(k, {}).values()) or [None])[0],
                 "write_size_kb": (list(wr.get(k, {}).values()) or [None])[0],
+                # average duration of the kernel in the kernel trace of the timed bench command of this
+                # schedule (kernels of neighbouring frames and streams overlapping, as in the bench)
+                "trace_avg_ns": tr.get(k.replace("wr::", "")),
             }
         out["schedules"][n] = ks
     path = os.path.join(ROOT, "gpurun_out", f"{tag}_counters.json")

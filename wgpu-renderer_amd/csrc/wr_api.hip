@@ -54,7 +54,7 @@ constexpr int kShadowRasterThreads = WR_SHADOW_RASTER_THREADS;
 #define WR_NOISE_LEVEL_ENTRIES (4u << 20)
 #endif
 #ifndef WR_NOISE_POOL_ENTRIES
-#define WR_NOISE_POOL_ENTRIES (8u << 20)
+#define WR_NOISE_POOL_ENTRIES (12u << 20)
 #endif
 constexpr size_t kNoiseLevelEntries = WR_NOISE_LEVEL_ENTRIES;  // largest hash table of one noise level
 constexpr size_t kNoisePoolEntries = WR_NOISE_POOL_ENTRIES;    // all levels together (4 bytes each, per frame in flight)
@@ -678,8 +678,20 @@ bool fog_sample_bounds(const WrContext* ctx, const FrameConsts& fc, double lo[3]
     return true;
 }
 
-// Chooses which noise levels get a hash table this frame: a level is tabled when its lattice
-// over the box of fog_sample_bounds fits the per-level and pool budgets.
+// Chooses which noise levels get a hash table this frame.  A level whose lattice over the whole
+// box of fog_sample_bounds fits the per-level and pool budgets is tabled whole.  Of the levels
+// that do not fit, the coarsest ones get a table over a part of the box, as long as the pool has
+// room: the part within a distance R of the camera along every axis, R as large as the budget
+// allows.  Samples are dense where the rays are close together, near the camera (half of the fog
+// pixels of the reference's view start their march within 400 units of it), so a table that
+// covers a small share of the volume serves a large share of the samples; a sample outside a
+// table is evaluated directly, with the same result.
+#ifndef WR_NOISE_PARTIAL
+#define WR_NOISE_PARTIAL 1
+#endif
+#ifndef WR_NOISE_PARTIAL_MIN_ENTRIES
+#define WR_NOISE_PARTIAL_MIN_ENTRIES (1u << 18)
+#endif
 NoiseTables plan_noise_tables(const WrContext* ctx, const FrameRes* f, const FrameConsts& fc, uint32_t* max_entries) {
     NoiseTables nt;
     memset(&nt, 0, sizeof(nt));
@@ -689,30 +701,85 @@ NoiseTables plan_noise_tables(const WrContext* ctx, const FrameRes* f, const Fra
 #endif
     double lo[3], hi[3];
     if (!fog_sample_bounds(ctx, fc, lo, hi)) return nt;
-    const double grow = 0.0;
     const double drift[3] = {fc.drift_xy, fc.drift_xy, fc.drift_z};
     size_t used = 0;
+    // lattice box [l, l + n) of level (k, o) over the world-space box [blo, bhi]
+    auto lattice = [&](int k, int o, const double blo[3], const double bhi[3], long l[3], long n[3]) {
+        const double s = (k == 0 ? 0.01 : 0.05), m = (double)(1 << o);
+        for (int r = 0; r < 3; ++r) {
+            const double a = (blo[r] * s + drift[r]) * m, b = (bhi[r] * s + drift[r]) * m;
+            l[r] = (long)std::floor(a) - 1;
+            n[r] = (long)std::floor(b) + 2 - l[r] + 1;
+        }
+        return (double)n[0] * n[1] * n[2];
+    };
+    auto take = [&](int k, int o, const long l[3], const long n[3], double entries) {
+        NoiseTable& t = nt.level[k * 8 + o];
+        t.data = f->d_noise_pool + used;
+        t.lox = (int)l[0]; t.loy = (int)l[1]; t.loz = (int)l[2];
+        t.nx = (int)n[0]; t.ny = (int)n[1]; t.nz = (int)n[2];
+        used += (size_t)entries;
+        *max_entries = std::max<uint32_t>(*max_entries, (uint32_t)entries);
+    };
+    const double level_cap = (double)std::min(kNoiseLevelEntries, f->noise_pool_entries);
+    bool whole[16];
     for (int k = 0; k < 2; ++k)
         for (int o = 0; o < 8; ++o) {
-            const double s = (k == 0 ? 0.01 : 0.05), m = (double)(1 << o);
             long l[3], n[3];
-            for (int r = 0; r < 3; ++r) {
-                double a = ((lo[r] - grow) * s + drift[r]) * m, b = ((hi[r] + grow) * s + drift[r]) * m;
-                l[r] = (long)std::floor(a) - 1;
-                n[r] = (long)std::floor(b) + 2 - l[r] + 1;
-            }
-            double entries = (double)n[0] * n[1] * n[2];
+            const double entries = lattice(k, o, lo, hi, l, n);
 #ifdef WR_DEV
             if (getenv("WR_DEBUG_TABLES")) fprintf(stderr, "noise level %d/%d: %ld x %ld x %ld = %.0f entries\n", k, o, n[0], n[1], n[2], entries);
 #endif
-            if (entries > (double)std::min(kNoiseLevelEntries, f->noise_pool_entries) || used + (size_t)entries > f->noise_pool_entries) continue;
-            NoiseTable& t = nt.level[k * 8 + o];
-            t.data = f->d_noise_pool + used;
-            t.lox = (int)l[0]; t.loy = (int)l[1]; t.loz = (int)l[2];
-            t.nx = (int)n[0]; t.ny = (int)n[1]; t.nz = (int)n[2];
-            used += (size_t)entries;
-            *max_entries = std::max<uint32_t>(*max_entries, (uint32_t)entries);
+            whole[k * 8 + o] = !(entries > level_cap || used + (size_t)entries > f->noise_pool_entries);
+            if (whole[k * 8 + o]) take(k, o, l, n, entries);
         }
+    if (!WR_NOISE_PARTIAL) return nt;
+    // Partial tables, coarsest cells first (cell size of level (k, o): 100 / 2^o and 20 / 2^o
+    // units).  The second fbm's cells count double: its octaves run for about nine samples in
+    // ten, the first fbm's fine octaves for four in ten (its coarse octaves decide most samples).
+    // A part that reaches less than 100 units into the box is not worth its entries.
+    double reach_needed = 0.0;
+    for (int r = 0; r < 3; ++r)
+        reach_needed = std::max(reach_needed, std::max(lo[r] - (double)fc.cam_pos[r], (double)fc.cam_pos[r] - hi[r]));
+    reach_needed = std::max(reach_needed, 0.0) + 100.0;
+    for (int rank = 0; rank < 16; ++rank) {
+        int best = -1;
+        double best_cell = 0.0;
+        for (int l = 0; l < 16; ++l) {
+            const double cell = (l < 8 ? 100.0 : 40.0) / (double)(1 << (l & 7));
+            if (!whole[l] && nt.level[l].data == nullptr && cell > best_cell) { best = l; best_cell = cell; }
+        }
+        if (best < 0) break;
+        whole[best] = true;  // (looked at)
+        const int k = best >> 3, o = best & 7;
+        const double budget = std::min(level_cap, (double)(f->noise_pool_entries - used));
+        if (budget < (double)WR_NOISE_PARTIAL_MIN_ENTRIES) break;
+        // the largest R whose box (the bounds within R of the camera along every axis) fits the budget
+        auto box_of = [&](double R, double blo[3], double bhi[3]) {
+            for (int r = 0; r < 3; ++r) {
+                blo[r] = std::max(lo[r], (double)fc.cam_pos[r] - R);
+                bhi[r] = std::min(hi[r], (double)fc.cam_pos[r] + R);
+                if (!(blo[r] <= bhi[r])) return false;
+            }
+            return true;
+        };
+        double r_ok = 0.0, r_lo = 0.0, r_hi = 1.0e5;
+        for (int it = 0; it < 40; ++it) {
+            const double R = 0.5 * (r_lo + r_hi);
+            double blo[3], bhi[3];
+            long l[3], n[3];
+            if (!box_of(R, blo, bhi) || lattice(k, o, blo, bhi, l, n) <= budget) { r_ok = R; r_lo = R; } else r_hi = R;
+        }
+        double blo[3], bhi[3];
+        long l[3], n[3];
+        if (r_ok < reach_needed || !box_of(r_ok, blo, bhi)) continue;
+        const double entries = lattice(k, o, blo, bhi, l, n);
+        if (entries > budget || n[0] < 3 || n[1] < 3 || n[2] < 3) continue;
+#ifdef WR_DEV
+        if (getenv("WR_DEBUG_TABLES")) fprintf(stderr, "noise level %d/%d: part within %.0f units of the camera, %ld x %ld x %ld = %.0f entries\n", k, o, r_ok, n[0], n[1], n[2], entries);
+#endif
+        take(k, o, l, n, entries);
+    }
     return nt;
 }
 
