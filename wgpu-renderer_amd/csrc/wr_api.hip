@@ -146,6 +146,7 @@ struct FrameRes {
 
     VertexOut vout{};
     WsAlloc geom, shadow, fog;
+    uint32_t* d_shadow_pairs = nullptr;  // [6 * triangles] (triangle, face) pairs the shadow passes set up this frame
     uint32_t* d_vis = nullptr;
     float* d_depth = nullptr;
     uint32_t* d_color = nullptr;
@@ -291,6 +292,7 @@ void free_scene(WrContext* c) {
     for (FrameRes& f : c->fr) {
         dfree(f.vout.clip); dfree(f.vout.v0); dfree(f.vout.v1); dfree(f.vout.v2); dfree(f.vout.v3);
         free_ws(f.geom); free_ws(f.shadow); free_ws(f.fog);
+        dfree(f.d_shadow_pairs);
     }
 }
 
@@ -395,7 +397,10 @@ int alloc_frame_scene(WrContext* ctx, Arena& ar, FrameRes* f) {
         const int bs = (ctx->S + kBin - 1) / kBin;
         const uint64_t items = 6u * (4u * slots + 64u * (uint64_t)(bs * bs) + (1u << 18));
         if (6 * (slots + ovf) > 0xFFFFFFF0ull || items > 0xFFFFFFF0ull) return fail(ctx, WR_ERR_UNSUPPORTED, "geometry too large for the 32-bit bin lists");
-        if ((rc = alloc_ws(ctx, ar, f->shadow, (uint32_t)slots, (uint32_t)ovf, (uint32_t)items, bs, bs, 6, err, err + 2)) != WR_OK) return rc;
+        // (one extra counter word behind the per-face clip counts: the length of the pair list)
+        if ((rc = alloc_ws(ctx, ar, f->shadow, (uint32_t)slots, (uint32_t)ovf, (uint32_t)items, bs, bs, 6, err, err + 2, 1)) != WR_OK) return rc;
+        if (!ar.carving()) dfree(f->d_shadow_pairs);
+        WR_HIP(arena_take(ar, f->d_shadow_pairs, sizeof(uint32_t) * 6 * (size_t)slots));
     }
     {
         const uint32_t slots = std::max(ntf, 1u);
@@ -583,8 +588,16 @@ int shadow_stage(WrContext* ctx, FrameRes* f, hipStream_t st, const FrameConsts&
     ShadowXf xf;
     memcpy(xf.model, fc.model_geom, sizeof(xf.model));
     memcpy(xf.light, fc.light_m, sizeof(xf.light));
+    uint32_t* pair_count = f->shadow.ws.clip_count + 6;  // cleared with the pass's counters
+#ifdef WR_SHADOW_SETUP_PER_FACE
     hipLaunchKernelGGL(k_setup<true>, grid1(g.ntris, 6), dim3(256), 0, st, g.pos, g.idx, g.ntris,
                        f->shadow.ws, ctx->S, ctx->S, 0, 1, xf);
+    (void)pair_count;
+#else
+    hipLaunchKernelGGL(k_shadow_classify, grid1(g.ntris), dim3(256), 0, st, g.pos, g.idx, g.ntris, f->shadow.ws, xf, pair_count, f->d_shadow_pairs);
+    hipLaunchKernelGGL(k_setup_pairs, grid1(std::max(2u * g.ntris, 256u)), dim3(256), 0, st, g.pos, g.idx, f->shadow.ws, ctx->S, ctx->S, xf, pair_count,
+                       f->d_shadow_pairs);
+#endif
     hipLaunchKernelGGL(k_setup_clip<true>, dim3(128, 6, 1), dim3(64), 0, st, g.pos, g.idx, f->shadow.ws,
                        ctx->S, ctx->S, 0, 1, xf);
     return bin_and_raster(ctx, f, st, f->shadow, true, 0, 1, prev_done);

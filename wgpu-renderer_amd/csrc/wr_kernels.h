@@ -358,6 +358,76 @@ __global__ __launch_bounds__(256) void k_setup(const float4* verts, const uint32
     if (deferred) ws.clip_queue[(size_t)layer * ws.slots + k] = t;
 }
 
+// The shadow passes' set-up in two steps.  A triangle lies in the frustum of one or two of the six
+// cube faces and outside the others, so a thread per (triangle, face) pair fetched every triangle
+// six times to drop it five times.  k_shadow_classify fetches a triangle once, classifies it
+// against all six faces (the same two matrix products per vertex and face and the same
+// classify_triangle as the set-up proper, so the same decisions), marks the slots of the faces
+// that drop it and lists the other (triangle, face) pairs; k_setup_pairs sets those up, one
+// thread per listed pair.  The list's length is only known on the device: the grid has a fixed
+// size and its workgroups stride over the list.
+constexpr uint32_t kPairFaceShift = 29;  // pair = triangle | face << 29 (a context holds fewer than 2^29 triangles)
+__global__ __launch_bounds__(256) void k_shadow_classify(const float4* verts, const uint32_t* idx, uint32_t ntris, RasterWS ws,
+                                                         ShadowXf xf, uint32_t* pair_count, uint32_t* pairs) {
+    latency_bound_kernel();
+    __shared__ uint32_t s_cnt, s_base;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t faces = 0u;
+    if (t < ntris) {
+        V4 wp[3];
+        for (int k = 0; k < 3; ++k) {
+            const float4 p = verts[idx[3 * t + k]];
+            wp[k] = mat4_mul(xf.model, V4{p.x, p.y, p.z, 1.0f});
+        }
+        const size_t stride = (size_t)ws.slots + ws.ovf_cap;
+#pragma unroll
+        for (int f = 0; f < 6; ++f) {
+            V4 c[3];
+            for (int k = 0; k < 3; ++k) c[k] = mat4_mul(xf.light[f], wp[k]);
+            if (classify_triangle(c) != 0) faces |= 1u << f;
+            else ws.bb[(size_t)f * stride + t] = make_uint2(kBBInvalid, kBBNothing);
+        }
+    }
+    uint32_t k = group_append(pair_count, (uint32_t)__builtin_popcount(faces), &s_cnt, &s_base);
+#pragma unroll
+    for (uint32_t f = 0; f < 6u; ++f)
+        if ((faces >> f) & 1u) pairs[k++] = t | (f << kPairFaceShift);
+}
+__global__ __launch_bounds__(256) void k_setup_pairs(const float4* verts, const uint32_t* idx, RasterWS ws, int W, int H, ShadowXf xf,
+                                                     const uint32_t* pair_count, const uint32_t* pairs) {
+    latency_bound_kernel();
+    const uint32_t n = *pair_count;
+    // (the grid is sized for about two faces per triangle; a workgroup takes every gridDim.x-th
+    // group of 256 pairs, all its threads going round together)
+    for (uint32_t k0 = blockIdx.x * blockDim.x; k0 < n; k0 += gridDim.x * blockDim.x) {
+        const uint32_t k = k0 + threadIdx.x;
+        const bool have = k < n;
+        const uint32_t pr = have ? pairs[k] : 0u;
+        const uint32_t t = pr & ((1u << kPairFaceShift) - 1u), layer = pr >> kPairFaceShift;
+        V4 c[3];
+        if (have)
+            for (int j = 0; j < 3; ++j) c[j] = setup_vertex<true>(verts, idx[3 * t + j], layer, xf);
+        SetupTarget tg = setup_target(ws, layer, W, H, 0, 1);
+        const bool deferred = emit_triangle<true, true>(have, c, t, t, ws, tg);
+        // triangles that need the clipper: queued per face, one atomic per face and wavefront
+        if (__any(deferred ? 1 : 0)) {
+            const int lane = (int)(threadIdx.x & 63u);
+            for (uint32_t l = 0; l < 6u; ++l) {
+                const unsigned long long m = __ballot(deferred && layer == l);
+                if (!m) continue;
+                const int leader = (int)__builtin_ctzll(m);
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(&ws.clip_count[l], (uint32_t)__popcll(m));
+                base = (uint32_t)__shfl((int)base, leader);
+                if (deferred && layer == l) {
+                    const uint32_t q = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (q < ws.slots) ws.clip_queue[(size_t)l * ws.slots + q] = t;
+                }
+            }
+        }
+    }
+}
+
 // The triangles k_setup queued: clipped against the near, far and guard-band planes, their fan
 // triangles set up and counted into the bins.
 template <bool SHADOW>
