@@ -7,6 +7,40 @@
 #include "../../wgpu-renderer_amd/csrc/wr_device.h"
 using namespace wr;
 
+// Same 28-word-per-sub-triangle layout as the oracle's wro_setup_triangle.
+WR_HD int setup_triangle_words(const float* clip, unsigned W, unsigned H, int shadow, unsigned* out, int max_subs) {
+    V4 c[3];
+    for (int k = 0; k < 3; ++k) c[k] = V4{clip[4 * k], clip[4 * k + 1], clip[4 * k + 2], clip[4 * k + 3]};
+    int cls = classify_triangle(c);
+    if (cls == 0) return 0;
+    ClipVert poly[10];
+    for (int k = 0; k < 3; ++k) {
+        poly[k].x = c[k].x; poly[k].y = c[k].y; poly[k].z = c[k].z; poly[k].w = c[k].w;
+        poly[k].b0 = k == 0; poly[k].b1 = k == 1; poly[k].b2 = k == 2;
+    }
+    int n = 3;
+    if (cls == 2) { n = clip_polygon(poly, 3); if (n < 3) return 0; }
+    int cnt = 0;
+    for (int i = 1; i + 1 < n && cnt < max_subs; ++i) {
+        ClipVert cv[3] = {poly[0], poly[i], poly[i + 1]};
+        Rec r; float beta[9];
+        if (!setup_sub(cv, (int)W, (int)H, shadow != 0, (unsigned)(i - 1), r, beta)) continue;
+        unsigned* w = out + (size_t)cnt * 28;
+        w[0] = r.X0; w[1] = r.Y0; w[2] = r.X1; w[3] = r.Y1; w[4] = r.X2; w[5] = r.Y2;
+        w[6] = f2u(r.z0); w[7] = f2u(r.dz1); w[8] = f2u(r.dz2); w[9] = f2u(r.inv2A);
+        if (shadow) {  // bias lives in iw0 for shadow records
+            w[10] = 0; w[11] = f2u(r.iw1); w[12] = f2u(r.iw2); w[13] = f2u(r.iw0);
+        } else {
+            w[10] = f2u(r.iw0); w[11] = f2u(r.iw1); w[12] = f2u(r.iw2); w[13] = 0;
+        }
+        w[14] = r.id & 7u; w[15] = r.bbmin & 0xffffu; w[16] = r.bbmin >> 16; w[17] = r.bbmax & 0xffffu; w[18] = r.bbmax >> 16;
+        for (int k = 0; k < 9; ++k) w[19 + k] = f2u(beta[k]);
+        ++cnt;
+    }
+    return cnt;
+}
+
+
 // Device-side unit checks (GPU tests only): the same functions evaluated by a kernel.
 __global__ void k_hc_hash(const float* d, int n, float* out_guarded, float* out_unguarded) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -33,6 +67,95 @@ __global__ void k_hc_fract(unsigned long long* mismatches) {
     }
     if (bad) atomicAdd(mismatches, bad);
 }
+
+
+// The rest of the arithmetic, evaluated by kernels over arrays of inputs (GPU tests compare the
+// results with the oracle's for the same inputs).  One item per thread, 256 threads per group,
+// so that neighbouring lanes of a wavefront hold unrelated items: the worst case for whatever
+// a function decides per wavefront (the early end of fbm's octave loop).
+__global__ void k_hc_noise(const float* p, int n, float time, float drift_z, float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    FrameConsts fc; memset(&fc, 0, sizeof(fc));
+    fc.time = time; fc.drift_xy = time * 0.2f; fc.drift_z = drift_z;
+    const V3 q = v3(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
+    out[3 * i] = value_noise(q);
+    out[3 * i + 1] = fbm(q * 0.05f);
+    out[3 * i + 2] = fog_noise(fc, q);
+}
+// 17 floats in (n, l, v, h, albedo, roughness, metalness), 3 out
+__global__ void k_hc_brdf(const float* in, int n, float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* b = in + 17 * (size_t)i;
+    V3 r = brdf(v3(b[0], b[1], b[2]), v3(b[3], b[4], b[5]), v3(b[6], b[7], b[8]), v3(b[9], b[10], b[11]), v3(b[12], b[13], b[14]), b[15], b[16]);
+    out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+}
+// 6 floats in (light colour rgba, distance, surface-light dot), 3 out
+__global__ void k_hc_ambient(const float* in, int n, float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 r = sample_ambient_light(in + 6 * (size_t)i, in[6 * (size_t)i + 4], in[6 * (size_t)i + 5]);
+    out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+}
+__global__ void k_hc_scalars(const float* x, int n, const float* tables, float zn, float zf, uint32_t* codes, float* linear) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ColorTables ct{tables};
+    codes[i] = srgb_encode(ct, x[i]);
+    linear[i] = depth_to_linear(x[i], zn, zf);
+}
+// Every f32 bit pattern: the device's srgb_encode (search from a hardware log2/exp2 estimate)
+// against the definition, the largest code whose threshold is at most x, found by a plain scan.
+__global__ void k_hc_srgb_all(const float* tables, unsigned long long* mismatches) {
+    ColorTables ct{tables};
+    unsigned long long bad = 0;
+    for (unsigned long long b = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b < (1ull << 32);
+         b += (unsigned long long)gridDim.x * blockDim.x) {
+        const float x = u2f((uint32_t)b);
+        uint32_t want = 0;
+        if (x >= 1.0f) want = 255;
+        else if (x > 0.0f) {
+            for (uint32_t c = 1; c < 256 && x >= ct.thresh(c); ++c) want = c;
+        }
+        if (srgb_encode(ct, x) != want) ++bad;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+// dst code word + 4 source floats + blend flag in, packed code word out
+__global__ void k_hc_blend(const uint32_t* dst, const float* src, const int* blend, int n, const float* tables, uint32_t* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ColorTables ct{tables};
+    out[i] = blend_pack(ct, dst[i], V4{src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]}, blend[i] != 0);
+}
+// hc_setup_triangle per thread: 12 clip floats in, up to 8 sub-triangles of 28 words out
+__global__ void k_hc_setup(const float* clip, int n, unsigned W, unsigned H, int shadow, unsigned* out, int* counts) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    counts[i] = setup_triangle_words(clip + 12 * (size_t)i, W, H, shadow, out + (size_t)i * 8 * 28, 8);
+}
+
+namespace {
+// Device buffers of one call: freed when the call returns, whatever path it takes.
+struct DevBufs {
+    void* p[8] = {};
+    int n = 0;
+    hipError_t err = hipSuccess;
+    template <typename T> T* make(size_t count, const T* init = nullptr) {
+        void* d = nullptr;
+        if (err == hipSuccess) err = hipMalloc(&d, count * sizeof(T) + 16);
+        if (err == hipSuccess && init) err = hipMemcpy(d, init, count * sizeof(T), hipMemcpyHostToDevice);
+        if (d) p[n++] = d;
+        return (T*)d;
+    }
+    template <typename T> void fetch(T* host, const T* dev, size_t count) {
+        if (err == hipSuccess) err = hipDeviceSynchronize();
+        if (err == hipSuccess) err = hipMemcpy(host, dev, count * sizeof(T), hipMemcpyDeviceToHost);
+    }
+    ~DevBufs() { for (int i = 0; i < n; ++i) (void)hipFree(p[i]); }
+};
+}  // namespace
 
 extern "C" {
 // returns 0, or the HIP error code
@@ -151,37 +274,79 @@ static void tables() {
 unsigned hc_srgb_encode(float x) { tables(); ColorTables ct{g_tables}; return srgb_encode(ct, x); }
 unsigned hc_blend_pack(unsigned dst, const float* src, int blend) { tables(); ColorTables ct{g_tables}; return blend_pack(ct, dst, V4{src[0], src[1], src[2], src[3]}, blend != 0); }
 
-// Same 28-word-per-sub-triangle layout as the oracle's wro_setup_triangle.
 int hc_setup_triangle(const float* clip, unsigned W, unsigned H, int shadow, unsigned* out, int max_subs) {
-    V4 c[3];
-    for (int k = 0; k < 3; ++k) c[k] = V4{clip[4 * k], clip[4 * k + 1], clip[4 * k + 2], clip[4 * k + 3]};
-    int cls = classify_triangle(c);
-    if (cls == 0) return 0;
-    ClipVert poly[10];
-    for (int k = 0; k < 3; ++k) {
-        poly[k].x = c[k].x; poly[k].y = c[k].y; poly[k].z = c[k].z; poly[k].w = c[k].w;
-        poly[k].b0 = k == 0; poly[k].b1 = k == 1; poly[k].b2 = k == 2;
-    }
-    int n = 3;
-    if (cls == 2) { n = clip_polygon(poly, 3); if (n < 3) return 0; }
-    int cnt = 0;
-    for (int i = 1; i + 1 < n && cnt < max_subs; ++i) {
-        ClipVert cv[3] = {poly[0], poly[i], poly[i + 1]};
-        Rec r; float beta[9];
-        if (!setup_sub(cv, (int)W, (int)H, shadow != 0, (unsigned)(i - 1), r, beta)) continue;
-        unsigned* w = out + (size_t)cnt * 28;
-        w[0] = r.X0; w[1] = r.Y0; w[2] = r.X1; w[3] = r.Y1; w[4] = r.X2; w[5] = r.Y2;
-        w[6] = f2u(r.z0); w[7] = f2u(r.dz1); w[8] = f2u(r.dz2); w[9] = f2u(r.inv2A);
-        if (shadow) {  // bias lives in iw0 for shadow records
-            w[10] = 0; w[11] = f2u(r.iw1); w[12] = f2u(r.iw2); w[13] = f2u(r.iw0);
-        } else {
-            w[10] = f2u(r.iw0); w[11] = f2u(r.iw1); w[12] = f2u(r.iw2); w[13] = 0;
-        }
-        w[14] = r.id & 7u; w[15] = r.bbmin & 0xffffu; w[16] = r.bbmin >> 16; w[17] = r.bbmax & 0xffffu; w[18] = r.bbmax >> 16;
-        for (int k = 0; k < 9; ++k) w[19 + k] = f2u(beta[k]);
-        ++cnt;
-    }
-    return cnt;
+    return setup_triangle_words(clip, W, H, shadow, out, max_subs);
+}
+// Device forms: every function returns 0 or the HIP error code.
+int hc_dev_noise(const float* p, int n, float time, float* out) {
+    DevBufs b;
+    float* dp = b.make<float>(3 * (size_t)n, p);
+    float* dout = b.make<float>(3 * (size_t)n);
+    if (b.err == hipSuccess) k_hc_noise<<<(n + 255) / 256, 256>>>(dp, n, time, wr_sin(time * 0.1f) * 0.5f, dout);
+    b.fetch(out, dout, 3 * (size_t)n);
+    return (int)b.err;
+}
+int hc_dev_brdf(const float* in, int n, float* out) {
+    DevBufs b;
+    float* din = b.make<float>(17 * (size_t)n, in);
+    float* dout = b.make<float>(3 * (size_t)n);
+    if (b.err == hipSuccess) k_hc_brdf<<<(n + 255) / 256, 256>>>(din, n, dout);
+    b.fetch(out, dout, 3 * (size_t)n);
+    return (int)b.err;
+}
+int hc_dev_ambient(const float* in, int n, float* out) {
+    DevBufs b;
+    float* din = b.make<float>(6 * (size_t)n, in);
+    float* dout = b.make<float>(3 * (size_t)n);
+    if (b.err == hipSuccess) k_hc_ambient<<<(n + 255) / 256, 256>>>(din, n, dout);
+    b.fetch(out, dout, 3 * (size_t)n);
+    return (int)b.err;
+}
+int hc_dev_scalars(const float* x, int n, float zn, float zf, unsigned* codes, float* linear) {
+    tables();
+    DevBufs b;
+    float* dx = b.make<float>((size_t)n, x);
+    float* dt = b.make<float>(768, g_tables);
+    uint32_t* dc = b.make<uint32_t>((size_t)n);
+    float* dl = b.make<float>((size_t)n);
+    if (b.err == hipSuccess) k_hc_scalars<<<(n + 255) / 256, 256>>>(dx, n, dt, zn, zf, dc, dl);
+    b.fetch(codes, dc, (size_t)n);
+    b.fetch(linear, dl, (size_t)n);
+    return (int)b.err;
+}
+long long hc_dev_srgb_encode_mismatches() {
+    tables();
+    DevBufs b;
+    float* dt = b.make<float>(768, g_tables);
+    unsigned long long zero = 0, m = 0;
+    unsigned long long* dm = b.make<unsigned long long>(1, &zero);
+    if (b.err == hipSuccess) k_hc_srgb_all<<<8192, 256>>>(dt, dm);
+    b.fetch(&m, dm, 1);
+    return b.err == hipSuccess ? (long long)m : -1;
+}
+int hc_dev_blend_pack(const unsigned* dst, const float* src, const int* blend, int n, unsigned* out) {
+    tables();
+    DevBufs b;
+    uint32_t* dd = b.make<uint32_t>((size_t)n, dst);
+    float* ds = b.make<float>(4 * (size_t)n, src);
+    int* db = b.make<int>((size_t)n, blend);
+    float* dt = b.make<float>(768, g_tables);
+    uint32_t* dout = b.make<uint32_t>((size_t)n);
+    if (b.err == hipSuccess) k_hc_blend<<<(n + 255) / 256, 256>>>(dd, ds, db, n, dt, dout);
+    b.fetch(out, dout, (size_t)n);
+    return (int)b.err;
+}
+// n triangles of 12 clip floats; out holds 8 * 28 words per triangle, counts one int per triangle
+int hc_dev_setup_triangles(const float* clip, int n, unsigned W, unsigned H, int shadow, unsigned* out, int* counts) {
+    DevBufs b;
+    float* dc = b.make<float>(12 * (size_t)n, clip);
+    unsigned* dout = b.make<unsigned>((size_t)n * 8 * 28);
+    int* dn = b.make<int>((size_t)n);
+    if (b.err == hipSuccess) b.err = hipMemset(dout, 0, (size_t)n * 8 * 28 * 4);
+    if (b.err == hipSuccess) k_hc_setup<<<(n + 255) / 256, 256>>>(dc, n, W, H, shadow, dout, dn);
+    b.fetch(out, dout, (size_t)n * 8 * 28);
+    b.fetch(counts, dn, (size_t)n);
+    return (int)b.err;
 }
 // coverage + depth + barycentrics of one pixel for the first sub-triangle: returns 1 if covered
 int hc_fragment(const float* clip, unsigned W, unsigned H, int px, int py, float* out_z, float* out_B) {

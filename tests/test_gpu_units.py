@@ -1,0 +1,185 @@
+"""The product's arithmetic (wgpu-renderer_amd/csrc/wr_device.h) as the device compiles and runs
+it, one function at a time, against the oracle on the same inputs, bit for bit.
+
+tests/test_oracle.py makes the same comparisons with the HOST build of that header; a few
+functions take another route on the device (the sRGB encoder's search from a hardware estimate,
+fbm's octave loop ending per wavefront, the hardware's division, square root and fraction), and
+this file covers those routes with kernels that evaluate single functions
+(tests/hostcheck/hostcheck.hip, hc_dev_*).  Full frames are compared elsewhere
+(tests/test_gpu_parity.py); a unit comparison says which function is off when a frame is."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from golden_inputs import unit_inputs
+from oracle_lib import f3, lib as oracle_handle
+
+pytestmark = pytest.mark.gpu
+HC_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostcheck", "libwr_hostcheck.so")
+fp = C.POINTER(C.c_float)
+up = C.POINTER(C.c_uint32)
+
+
+def ptr(a, t=fp):
+    return a.ctypes.data_as(t)
+
+
+@pytest.fixture(scope="module")
+def H():
+    h = C.CDLL(HC_PATH)
+    h.hc_dev_noise.argtypes = [fp, C.c_int, C.c_float, fp]
+    h.hc_dev_brdf.argtypes = [fp, C.c_int, fp]
+    h.hc_dev_ambient.argtypes = [fp, C.c_int, fp]
+    h.hc_dev_scalars.argtypes = [fp, C.c_int, C.c_float, C.c_float, up, fp]
+    h.hc_dev_srgb_encode_mismatches.restype = C.c_longlong
+    h.hc_dev_blend_pack.argtypes = [up, fp, C.POINTER(C.c_int), C.c_int, up]
+    h.hc_dev_setup_triangles.argtypes = [fp, C.c_int, C.c_uint32, C.c_uint32, C.c_int, up, C.POINTER(C.c_int)]
+    h.hc_blend_pack.restype = C.c_uint
+    h.hc_blend_pack.argtypes = [C.c_uint, fp, C.c_int]
+    return h
+
+
+@pytest.fixture(scope="module")
+def L():
+    return oracle_handle()
+
+
+def same_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+def test_noise_family_on_the_device(H, L):
+    """value_noise, fbm, fog_noise (noise.wgsl:7-40, fog.wgsl:48-62) at points of the fog volume
+    and far outside it (every tier of the sine; lanes of a wavefront hold unrelated points, so
+    the wavefront-wide early end of the octave loop meets lanes that are not decided)."""
+    rng = np.random.default_rng(21)
+    pts = np.concatenate([unit_inputs()["points"],
+                          rng.uniform([-1360, -90, -600], [1360, 60, 600], (12000, 3)),
+                          rng.uniform(-3000, 3000, (4000, 3)),
+                          rng.uniform(-3.0e5, 3.0e5, (2000, 3)),       # beyond the fast sine's range
+                          rng.uniform(-4.0e7, 4.0e7, (1000, 3)),       # beyond the unguarded sine's range
+                          np.array([[0, 0, 0], [-0.0, 1e-30, -1e-30], [199.99 / 0.05, 0, 0], [200.0 / 0.05, 0, 0], [16000 / 0.05, 1, 1]])]).astype(np.float32)
+    n, time = len(pts), 7.5
+    got = np.empty((n, 3), np.float32)
+    assert H.hc_dev_noise(ptr(np.ascontiguousarray(pts)), n, time, ptr(got)) == 0
+    want = np.empty((n, 3), np.float32)
+    f32 = np.float32
+    for i, p in enumerate(pts):
+        want[i, 0] = L.wro_value_noise(f3(p))
+        want[i, 1] = L.wro_fbm(f3(p * f32(0.05)))
+        want[i, 2] = L.wro_fog_noise(f3(p), time)
+    for k, name in enumerate(("value_noise", "fbm", "fog_noise")):
+        assert same_bits(got[:, k], want[:, k]), name
+    assert 0.02 < (want[:, 1] == 0).mean() < 0.98  # saturated and unsaturated sums both occur
+
+
+def test_shading_terms_on_the_device(H, L):
+    """brdf (pbr.wgsl:191-230), sample_ambient_light (light.wgsl), depth_to_linear (fog.wgsl:43-46)."""
+    rng = np.random.default_rng(22)
+    rows = list(unit_inputs()["brdf"])
+    for _ in range(20000):
+        nn, l, v = (rng.normal(size=3) for _ in range(3))
+        nn, l, v = nn / np.linalg.norm(nn), l / np.linalg.norm(l), v / np.linalg.norm(v)
+        hv = (l + v) / max(np.linalg.norm(l + v), 1e-9)
+        rows.append(np.concatenate([nn, l, v, hv, rng.uniform(0, 1, 3), [rng.choice([0.0, 0.02, 1.0, rng.uniform(0, 1)])], [rng.choice([0.0, 1.0, rng.uniform(0, 1)])]]))
+    b = np.ascontiguousarray(np.array(rows, np.float32))
+    n = len(b)
+    got = np.empty((n, 3), np.float32)
+    assert H.hc_dev_brdf(ptr(b), n, ptr(got)) == 0
+    want = np.empty((n, 3), np.float32)
+    o = (C.c_float * 3)()
+    for i, r in enumerate(b):
+        L.wro_brdf(f3(r[0:3]), f3(r[3:6]), f3(r[6:9]), f3(r[9:12]), f3(r[12:15]), float(r[15]), float(r[16]), o)
+        want[i] = o[:]
+    assert same_bits(got, want)
+
+    amb = list(unit_inputs()["ambient"])
+    for _ in range(5000):
+        amb.append(np.concatenate([rng.uniform(0, 1, 3), [rng.choice([250000.0, 1.0, 0.0])], [rng.choice([0.0, 1e-3, rng.uniform(1, 4000)])], [rng.uniform(-1, 1)]]))
+    a = np.ascontiguousarray(np.array(amb, np.float32))
+    got = np.empty((len(a), 3), np.float32)
+    assert H.hc_dev_ambient(ptr(a), len(a), ptr(got)) == 0
+    want = np.empty((len(a), 3), np.float32)
+    for i, r in enumerate(a):
+        L.wro_ambient((C.c_float * 4)(*r[0:4].tolist()), float(r[4]), float(r[5]), o)
+        want[i] = o[:]
+    assert same_bits(got, want)
+
+
+def test_colour_codes_and_linear_depth_on_the_device(H, L):
+    ui = unit_inputs()
+    rng = np.random.default_rng(23)
+    L.wro_srgb_encode.restype = C.c_uint8
+    L.wro_srgb_encode.argtypes = [C.c_float]
+    x = np.concatenate([ui["linear"], ui["depth"], rng.uniform(0, 1, 20000), rng.uniform(0, 0.01, 5000), rng.uniform(0.9, 1.0, 5000),
+                        [np.inf, -np.inf, 1e-38, 1e-45]]).astype(np.float32)
+    # thresholds of the codes themselves and their neighbours
+    thr = np.array([((c - 0.5) / 255.0) for c in range(1, 256)])
+    lin = np.where(thr <= 0.04045, thr / 12.92, ((thr + 0.055) / 1.055) ** 2.4).astype(np.float32)
+    x = np.ascontiguousarray(np.concatenate([x, lin, np.nextafter(lin, np.float32(0)), np.nextafter(lin, np.float32(1))]).astype(np.float32))
+    n = len(x)
+    codes = np.empty(n, np.uint32)
+    linear = np.empty(n, np.float32)
+    assert H.hc_dev_scalars(ptr(x), n, 1.0, 3000.0, ptr(codes, up), ptr(linear)) == 0
+    want_codes = np.array([L.wro_srgb_encode(float(v)) for v in x], np.uint32)
+    assert np.array_equal(codes, want_codes)
+    want_linear = np.array([L.wro_depth_to_linear(float(v), 1.0, 3000.0) for v in x], np.float32)
+    assert same_bits(linear, want_linear)
+
+
+def test_device_srgb_encoder_equals_its_definition_on_every_float(H):
+    """All 2^32 bit patterns: the device's search from a hardware log2/exp2 estimate returns the
+    largest code whose threshold is at most x (0 for x <= 0 and NaN, 255 from 1 upward)."""
+    assert H.hc_dev_srgb_encode_mismatches() == 0
+
+
+def test_blend_and_pack_on_the_device_equals_the_host_build(H):
+    """blend_pack (pass.rs:67-83 on the decoded 8-bit destination): device against the host build
+    of the same header, which the CPU tests compare with the oracle's frames."""
+    rng = np.random.default_rng(24)
+    n = 40000
+    dst = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+    src = rng.uniform(-0.1, 1.1, (n, 4)).astype(np.float32)
+    src[:200, 3] = rng.choice([0.0, 1.0, 0.5], 200)
+    blend = (rng.uniform(size=n) < 0.7).astype(np.int32)
+    out = np.empty(n, np.uint32)
+    assert H.hc_dev_blend_pack(ptr(dst, up), ptr(src), blend.ctypes.data_as(C.POINTER(C.c_int)), n, ptr(out, up)) == 0
+    want = np.array([H.hc_blend_pack(int(dst[i]), ptr(src[i]), int(blend[i])) for i in range(n)], np.uint32)
+    assert np.array_equal(out, want)
+
+
+def test_triangle_setup_on_the_device(H, L):
+    """Clipping, snapping, depth planes, clip weights and shadow bias of random triangles around a
+    perspective camera (many cross the near plane or the guard band), as set up by a kernel."""
+    rng = np.random.default_rng(25)
+    f, nr = 3000.0, 1.0
+    fl = 1 / np.tan(np.radians(55) / 2)
+    clips = [t[0] for t in unit_inputs()["triangles"]]
+    for _ in range(6000):
+        P = rng.uniform(-1, 1, (3, 3)) * 3 + np.array([0, 0, rng.uniform(-4, 2)])
+        clip = []
+        for k in range(3):
+            x, y, z = P[k] * rng.choice([1, 1, 1, 50])
+            clip += [fl / 1.777 * x, fl * y, (f + nr) / (nr - f) * z + 2 * f * nr / (nr - f), -z]
+        clips.append(clip)
+    c = np.ascontiguousarray(np.array(clips, np.float32))
+    n = len(c)
+    L.wro_setup_triangle.restype = C.c_int
+    L.wro_setup_triangle.argtypes = [fp, C.c_uint32, C.c_uint32, C.c_int, up, C.c_int]
+    total = 0
+    for shadow, (w, h) in ((0, (640, 360)), (1, (2048, 2048))):
+        out = np.empty((n, 8, 28), np.uint32)
+        counts = np.empty(n, np.int32)
+        assert H.hc_dev_setup_triangles(ptr(c), n, w, h, shadow, ptr(out, up), counts.ctypes.data_as(C.POINTER(C.c_int))) == 0
+        buf = np.empty((8, 28), np.uint32)
+        for i in range(n):
+            na = L.wro_setup_triangle(ptr(c[i]), w, h, shadow, ptr(buf, up), 8)
+            assert na == counts[i], i
+            A = buf[:na].copy()
+            if shadow:
+                A[:, 10] = 0  # shadow records do not keep 1/w of vertex 0 (the bias takes its slot)
+            assert np.array_equal(A, out[i, :na]), (i, shadow)
+            total += na
+    assert total > 4000
