@@ -134,7 +134,10 @@ typedef struct WrConfig {
      * ends.  No buffer is written before its last reader is done.)  2 to 4: consecutive frames rotate through that
      * many sets of frame buffers (about 1.5 GB each at 1080p) and overlap on the device; a
      * frame's results are complete after wr_sync (every wr_read_* and wr_get_stats syncs), and
-     * read-back / wr_color_device_ptr refer to the most recently submitted frame. */
+     * read-back / wr_color_device_ptr refer to the most recently submitted frame.  More than
+     * one frame in flight pays only when every stream has a HIP hardware queue of its own:
+     * export GPU_MAX_HW_QUEUES=16 before the process's first HIP call (HIP's default of 4 makes
+     * 2 to 4 frames in flight slower than 1). */
     uint32_t frames_in_flight;
     uint32_t reserved;
 } WrConfig;
