@@ -264,6 +264,20 @@ def timed(ranks, sync, body):
     return ranks.max_time(dt)
 
 
+def guarded(ranks, workload):
+    """A scale workload that fails must not take the frame line, measured before it, down with
+    it: the failure becomes the workload's entry.  The ranks agree on the outcome (a rank that
+    failed alone would leave the others waiting in the next barrier)."""
+    err, out = None, None
+    try:
+        out = workload()
+    except Exception as e:  # noqa: BLE001 (reported in the line, whatever it was)
+        err = f"{type(e).__name__}: {e}"
+    if ranks.max_time(1.0 if err else 0.0) > 0.0:
+        return {"error": err or "failed on another rank"}
+    return out
+
+
 def run_posebatch(ranks, sc, args, animate):
     """configs[4]: the 512-pose flythrough split contiguously over the ranks (total work fixed).
     Fixed t: wr_render_batch in groups of sixteen poses that share the group's shadow maps (the
@@ -313,7 +327,16 @@ def run_tiles4k(ranks, sc, args, steps):
     comm = None
     if world > 1:
         # the library's own communicator (wr_comm_*): rank 0 makes the id, gloo carries its 128 bytes
-        uid = ranks.from_root(abi.comm_unique_id() if ranks.rank == 0 else None)
+        uid = None
+        if ranks.rank == 0:
+            try:
+                uid = abi.comm_unique_id()
+            except abi.WrError as e:  # every rank must leave here together
+                uid = str(e)
+        uid = ranks.from_root(uid)
+        if isinstance(uid, str):
+            r.close()
+            raise RuntimeError(uid)
         comm = abi.comm_create(uid, ranks.rank, world, ranks.local_rank)
 
     def body():
@@ -457,9 +480,9 @@ def main(argv=None):
     scale_workloads = None
     if not args.no_scale_workloads and not args.sponza and args.detail == 1.0:
         scale_workloads = {
-            "posebatch": run_posebatch(ranks, sc, args, animate=False),
-            "posebatch_animated": run_posebatch(ranks, sc, args, animate=True),
-            "tiles4k": run_tiles4k(ranks, sc, args, steps=40) if not (args.share_device and world > 1) else None,
+            "posebatch": guarded(ranks, lambda: run_posebatch(ranks, sc, args, animate=False)),
+            "posebatch_animated": guarded(ranks, lambda: run_posebatch(ranks, sc, args, animate=True)),
+            "tiles4k": guarded(ranks, lambda: run_tiles4k(ranks, sc, args, steps=40)) if not (args.share_device and world > 1) else None,
         }
 
     total_frames = args.steps * world

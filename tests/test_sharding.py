@@ -209,6 +209,13 @@ def _ranks_worker(rank, world, port, q):
     try:
         r.barrier()
         got = (r.rank, r.world, r.max_time(1.0 + rank), r.from_root(b"id-%d" % rank if rank == 0 else None))
+
+        # a scale workload that fails on one rank only: every rank reports it and goes on
+        def fails_on_rank_one():
+            if rank == 1:
+                raise RuntimeError("no such device")
+            return {"value": 1.0}
+        got += (bench.guarded(r, fails_on_rank_one), bench.guarded(r, lambda: {"value": 2.0 + r.max_time(rank)}))
         q.put(got)
     finally:
         r.close()
@@ -228,4 +235,6 @@ def test_bench_ranks_talk_over_gloo():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert got == [(0, 2, 2.0, b"id-0"), (1, 2, 2.0, b"id-0")]
+    assert [g[:4] for g in got] == [(0, 2, 2.0, b"id-0"), (1, 2, 2.0, b"id-0")]
+    assert got[0][4] == {"error": "failed on another rank"} and got[1][4] == {"error": "RuntimeError: no such device"}
+    assert got[0][5] == got[1][5] == {"value": 3.0}
