@@ -1383,26 +1383,34 @@ int wr_render_frame_static(WrContext* ctx, const WrCameraUniform* camera, const 
     // array is touched only after the static frame before it has finished on the device.
     std::lock_guard<std::mutex> static_lock(g_scratch_mutex);
     const int dev = ctx->cfg.device;
-    if (g_static_recorded[dev]) WR_HIP(hipStreamWaitEvent(ctx->stream, g_static_done[dev], 0));
-    // The buffer keeps what the last call left: clear what a frame reads before writing it.
-    const size_t npx = (size_t)ctx->W * ctx->H;
-    WR_HIP(hipMemsetAsync(sf.blend.rp_slot, 0, npx * 4, ctx->stream));
-    ctx->stream_has_work = true;
-    if (!(passes & WR_PASS_SHADOWS)) {
-        const size_t ns = shadow_buffer_floats(ctx->S);
-        hipLaunchKernelGGL(k_fill_f32, dim3((uint32_t)((ns + 255) / 256)), dim3(256), 0, ctx->stream, sf.d_shadow, ns, 1.0f);
-    }
-    if ((rc = begin_counted(ctx)) != WR_OK) return rc;
-    FrameConsts fc = make_consts(ctx, camera, light, globals);
-    if ((rc = frame_stages(ctx, &sf, fc, passes, true)) != WR_OK) return rc;
-    WR_HIP(hipEventRecord(sf.ev_done, sf.cur_ms));
-    ctx->fr[0].submitted = true;
-    ++ctx->static_frames_submitted;
-    WR_HIP(hipStreamWaitEvent(ctx->stream, sf.ev_done, 0));
-    WR_HIP(hipEventRecord(g_static_done[dev], ctx->stream));
-    g_static_recorded[dev] = true;
-    ctx->stream_has_work = true;  // (the next frame must not touch the shared streams' buffers early)
-    return WR_OK;
+    auto submit = [&]() -> int {
+        if (g_static_recorded[dev]) WR_HIP(hipStreamWaitEvent(ctx->stream, g_static_done[dev], 0));
+        // The buffer keeps what the last call left: clear what a frame reads before writing it.
+        const size_t npx = (size_t)ctx->W * ctx->H;
+        WR_HIP(hipMemsetAsync(sf.blend.rp_slot, 0, npx * 4, ctx->stream));
+        ctx->stream_has_work = true;
+        if (!(passes & WR_PASS_SHADOWS)) {
+            const size_t ns = shadow_buffer_floats(ctx->S);
+            hipLaunchKernelGGL(k_fill_f32, dim3((uint32_t)((ns + 255) / 256)), dim3(256), 0, ctx->stream, sf.d_shadow, ns, 1.0f);
+        }
+        int rcs = begin_counted(ctx);
+        if (rcs != WR_OK) return rcs;
+        FrameConsts fc = make_consts(ctx, camera, light, globals);
+        if ((rcs = frame_stages(ctx, &sf, fc, passes, true)) != WR_OK) return rcs;
+        WR_HIP(hipEventRecord(sf.ev_done, sf.cur_ms));
+        ctx->fr[0].submitted = true;
+        ++ctx->static_frames_submitted;
+        WR_HIP(hipStreamWaitEvent(ctx->stream, sf.ev_done, 0));
+        WR_HIP(hipEventRecord(g_static_done[dev], ctx->stream));
+        g_static_recorded[dev] = true;
+        ctx->stream_has_work = true;  // (the next frame must not touch the shared streams' buffers early)
+        return WR_OK;
+    };
+    rc = submit();
+    // A call that failed half way may have queued work on the array that no event covers: the
+    // device is drained before the next caller gets the array.
+    if (rc != WR_OK) (void)sync_all(ctx);
+    return rc;
 }
 
 int wr_render_batch(WrContext* ctx, const WrCameraUniform* cameras, uint32_t count, const WrLightUniform* light,
