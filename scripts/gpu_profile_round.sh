@@ -3,7 +3,7 @@
 #   bash scripts/gpu_profile_round.sh r03
 # writes under gpurun_out/: TAG_kernel_stats.txt (default bench command, kernel trace),
 # TAG_one_frame_kernel_stats.txt + TAG_one_frame_timeline.txt (one frame in flight),
-# TAG_pmc_sq_{1,4}.txt, TAG_pmc_fetch_{1,4}.txt, TAG_pmc_write_{1,4}.txt (counter passes with
+# TAG_pmc_sq_{1,4}.txt, TAG_pmc_fetch_{1,4}.txt, TAG_pmc_write_{1,4}.txt, TAG_pmc_ta_tcp_{1,4}.txt (counter passes with
 # one and with four frames in flight: the two fog schedules run different kernels) and
 # TAG_counters.json (scripts/make_profile_json.py), which bench.py reads.
 # Every rocprofv3 run has the program directly after "--" and its own time limit; counter
@@ -30,5 +30,6 @@ for n in 1 4; do
   pmc pmc_sq_$n $n "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" || exit 1
   pmc pmc_fetch_$n $n "FETCH_SIZE" || exit 1
   pmc pmc_write_$n $n "WRITE_SIZE" || exit 1
+  pmc pmc_ta_tcp_$n $n "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_GATE_EN1_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE" || exit 1
 done
 cd $R && python3 scripts/make_profile_json.py $TAG

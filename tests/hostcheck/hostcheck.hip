@@ -225,7 +225,7 @@ float hc_fog_noise(const float* p, float time) {
 float hc_fog_noise_tab(const float* p, float time, int cap, int* tabled_levels) {
     FrameConsts fc; memset(&fc, 0, sizeof(fc));
     fc.time = time; fc.drift_xy = time * 0.2f; fc.drift_z = wr_sin(time * 0.1f) * 0.5f;
-    NoiseTables nt; memset(&nt, 0, sizeof(nt));
+    NoiseTables nt; memset(&nt, 0, sizeof(nt)); noise_tables_clear(nt);
     static float pool[1 << 16];
     size_t used = 0; int nlev = 0;
     const double drift[3] = {fc.drift_xy, fc.drift_xy, fc.drift_z};

@@ -58,6 +58,9 @@ constexpr int kShadowRasterThreads = WR_SHADOW_RASTER_THREADS;
 #endif
 constexpr size_t kNoiseLevelEntries = WR_NOISE_LEVEL_ENTRIES;  // largest hash table of one noise level
 constexpr size_t kNoisePoolEntries = WR_NOISE_POOL_ENTRIES;    // all levels together (4 bytes each, per frame in flight)
+#ifndef WR_TABLE_INDEX_64
+static_assert(kNoiseLevelEntries <= kNoiseTableMaxEntries, "value_noise_tab indexes a table with 24-bit multiplies");
+#endif
 static_assert(sizeof(FrameConsts) < 3072, "FrameConsts must fit the kernel argument segment");
 
 // Work buffers of wr_render_frame_static, the entry point for callers that cannot allocate.
@@ -708,10 +711,8 @@ bool fog_sample_bounds(const WrContext* ctx, const FrameConsts& fc, double lo[3]
 NoiseTables plan_noise_tables(const WrContext* ctx, const FrameRes* f, const FrameConsts& fc, uint32_t* max_entries) {
     NoiseTables nt;
     memset(&nt, 0, sizeof(nt));
+    noise_tables_clear(nt);
     *max_entries = 0;
-#ifdef WR_DEV
-    for (int l = 0; l < 16; ++l) nt.level[l].dbg_level = l;
-#endif
     double lo[3], hi[3];
     if (!fog_sample_bounds(ctx, fc, lo, hi)) return nt;
     const double drift[3] = {fc.drift_xy, fc.drift_xy, fc.drift_z};

@@ -789,6 +789,10 @@ struct NoiseTable {
     const float* data;   // nullptr: level not tabled
     int lox, loy, loz;   // lattice coordinate of entry (0,0,0)
     int nx, ny, nz;
+    // fbm_decided's bounds for this level's octave (set for every level, tabled or not, by
+    // noise_tables_clear): a partial sum at or below the first or at or above the second decides.
+    // They ride with the description, which the march fetches anyway with scalar loads.
+    float decided_low, decided_high;
 #ifdef WR_DEV
     int dbg_level, dbg_pad;  // level index, + 256 in the light-march kernel
 #endif
@@ -826,9 +830,55 @@ __device__ inline void wr_dbg_box(int level, float ux, float uy, float uz) {
 #else
 #define WR_DBG_LEVEL(level, direct) ((void)0)
 #endif
+#ifndef WR_TABLE_INDEX_64
+// Entries a table may hold at most: every dimension, every product of dimensions and every
+// byte offset into a table then fit the 24-bit multiplies and 32-bit offsets of value_noise_tab.
+constexpr uint32_t kNoiseTableMaxEntries = 1u << 24;
+WR_HD uint32_t mul24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return (a & 0xFFFFFFu) * (b & 0xFFFFFFu);
+#endif
+}
+WR_HD uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {  // a * b + c for a, b below 2^24
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;  // (as assembly: the compiler widens the nested form to a 64-bit multiply-add)
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    return (a & 0xFFFFFFu) * (b & 0xFFFFFFu) + c;
+#endif
+}
+#endif
 template <int GUARD>
 WR_HD float value_noise_tab(V3 p, const NoiseTable& t) {
     float ux = floorf(p.x), uy = floorf(p.y), uz = floorf(p.z);
+#ifndef WR_TABLE_INDEX_64
+    // The level's description, fetched in one piece (one scalar load and one wait on the device,
+    // where a field fetched inside each nested test was a wait per field).
+    const NoiseTable d = t;
+    // |u| < 2^24 here (the caller bounds |p|), so the conversions are exact
+    const int ix = (int)ux - d.lox, iy = (int)uy - d.loy, iz = (int)uz - d.loz;
+    const bool inside = ((unsigned)ix < (unsigned)(d.nx - 1)) & ((unsigned)iy < (unsigned)(d.ny - 1)) & ((unsigned)iz < (unsigned)(d.nz - 1));
+    if (d.data != nullptr && inside) {
+        float sx = smooth01(p.x - ux), sy = smooth01(p.y - uy), sz = smooth01(p.z - uz);
+        // inside the box every index, dimension and product below is under 2^24 (kNoiseTableMaxEntries)
+        const uint32_t row = (uint32_t)d.nx, slab = mul24((uint32_t)d.nx, (uint32_t)d.ny);
+        const uint32_t i0 = mad24(mad24((uint32_t)iz, (uint32_t)d.ny, (uint32_t)iy), row, (uint32_t)ix);
+        const char* base = reinterpret_cast<const char*>(d.data);
+        const float* q00 = reinterpret_cast<const float*>(base + (i0 << 2));
+        const float* q01 = reinterpret_cast<const float*>(base + ((i0 + row) << 2));
+        const float* q10 = reinterpret_cast<const float*>(base + ((i0 + slab) << 2));
+        const float* q11 = reinterpret_cast<const float*>(base + ((i0 + slab + row) << 2));
+        float a = q00[0], b = q00[1], c = q01[0], d_ = q01[1];
+        float e = q10[0], f = q10[1], g = q11[0], h = q11[1];
+#ifdef WR_DEV
+        WR_DBG_LEVEL(d.dbg_level, 0);
+#endif
+        return mixf(mixf(mixf(a, b, sx), mixf(c, d_, sx), sy), mixf(mixf(e, f, sx), mixf(g, h, sx), sy), sz);
+    }
+#else
     // |u| < 2^24 here (the caller bounds |p|), so the conversions are exact
     int ix = (int)ux - t.lox, iy = (int)uy - t.loy, iz = (int)uz - t.loz;
     if (t.data != nullptr && (unsigned)ix < (unsigned)(t.nx - 1) && (unsigned)iy < (unsigned)(t.ny - 1) &&
@@ -843,6 +893,7 @@ WR_HD float value_noise_tab(V3 p, const NoiseTable& t) {
 #endif
         return mixf(mixf(mixf(a, b, sx), mixf(c, d, sx), sy), mixf(mixf(e, f, sx), mixf(g, h, sx), sy), sz);
     }
+#endif
 #ifdef WR_DEV
     WR_DBG_LEVEL(t.dbg_level, 1);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -861,14 +912,34 @@ WR_HD float value_noise_tab(V3 p, const NoiseTable& t) {
 // stop only when every lane of the wavefront is decided (lanes of one wavefront are
 // neighbouring pixels, and the low octaves that decide vary slowly in space); a decided lane
 // that runs on still saturates to the same value.  NaN decides nothing.
-WR_HD bool fbm_decided(float ret, int i) {
-    const float rest = (0.5f / (float)(1 << i)) - 0.00390625f + 2.0e-6f;  // S_i + 2e-6
-    const bool dec = ret <= -rest || ret >= 1.0f + rest;
+#define WR_FBM_REST(i) ((0.5f / (float)(1 << (i))) - 0.00390625f + 2.0e-6f)  // S_i + 2e-6
+WR_HD bool fbm_decided_between(float ret, float low, float high) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __all(dec ? 1 : 0) != 0;
+    // every active lane decided, from the lane masks of the two comparisons (a vote on their
+    // disjunction is compiled to two more vector instructions)
+    return (__builtin_amdgcn_ballot_w64(ret <= low) | __builtin_amdgcn_ballot_w64(ret >= high)) == __builtin_amdgcn_ballot_w64(true);
 #else
-    return dec;
+    return ret <= low || ret >= high;
 #endif
+}
+WR_HD bool fbm_decided(float ret, int i) {
+    const float rest = WR_FBM_REST(i);
+    return fbm_decided_between(ret, -rest, 1.0f + rest);
+}
+// No level tabled; every level's bounds as fbm_decided computes them.
+WR_HD void noise_tables_clear(NoiseTables& nt) {
+    for (int l = 0; l < 16; ++l) {
+        NoiseTable& t = nt.level[l];
+        t.data = nullptr;
+        t.lox = t.loy = t.loz = 0;
+        t.nx = t.ny = t.nz = 0;
+        const float rest = WR_FBM_REST(l & 7);
+        t.decided_low = -rest;
+        t.decided_high = 1.0f + rest;
+#ifdef WR_DEV
+        t.dbg_level = l; t.dbg_pad = 0;
+#endif
+    }
 }
 template <int GUARD>
 WR_HD float fbm_t(V3 p) {
@@ -887,8 +958,15 @@ WR_HD float fbm_tab_t(V3 p, const NoiseTable* tabs) {
     float weight = 0.5f, ret = 0.0f;
     V3 q = p;
     for (int i = 0; i < 8; ++i) {
-        ret += weight * value_noise_tab<GUARD>(q, tabs[i]);
-        if (i < 7 && fbm_decided(ret, i)) break;
+        const NoiseTable& t = tabs[i];
+        float low = t.decided_low, high = t.decided_high;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // (the level index is the same in every lane: the two bounds are fetched here, next to
+        // the level's description, and not behind the noise, where their fetch would be waited for)
+        asm volatile("" : "+s"(low), "+s"(high));
+#endif
+        ret += weight * value_noise_tab<GUARD>(q, t);
+        if (i < 7 && fbm_decided_between(ret, low, high)) break;
         q = q * 2.0f;
         weight *= 0.5f;
     }

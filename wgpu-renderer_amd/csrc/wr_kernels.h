@@ -1703,6 +1703,10 @@ __global__ __launch_bounds__(256) void k_fog_shade_blend(FogArgs a) {
 // fill every slot to the end and suit a frame that has the device to itself.
 template <bool COUNT>
 __global__ __launch_bounds__(64) void k_fog_march(FogArgs a) {
+#ifdef WR_DEV_MARCH_VGPR
+    // developer experiment: a register the kernel does not need, to hold it to fewer wavefronts per SIMD
+    asm volatile("v_mov_b32 v" WR_DEV_MARCH_VGPR ", 0" ::: "v" WR_DEV_MARCH_VGPR);
+#endif
     const uint32_t k = blockIdx.x * 64u + threadIdx.x;
     if (k >= *a.item_count) return;
     const float4 ray = a.item_ray[k];
