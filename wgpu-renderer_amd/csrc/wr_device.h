@@ -857,26 +857,34 @@ WR_HD float value_noise_tab(V3 p, const NoiseTable& t) {
 #ifndef WR_TABLE_INDEX_64
     // The level's description, fetched in one piece (one scalar load and one wait on the device,
     // where a field fetched inside each nested test was a wait per field).
-    const NoiseTable d = t;
-    // |u| < 2^24 here (the caller bounds |p|), so the conversions are exact
-    const int ix = (int)ux - d.lox, iy = (int)uy - d.loy, iz = (int)uz - d.loz;
-    const bool inside = ((unsigned)ix < (unsigned)(d.nx - 1)) & ((unsigned)iy < (unsigned)(d.ny - 1)) & ((unsigned)iz < (unsigned)(d.nz - 1));
-    if (d.data != nullptr && inside) {
-        float sx = smooth01(p.x - ux), sy = smooth01(p.y - uy), sz = smooth01(p.z - uz);
-        // inside the box every index, dimension and product below is under 2^24 (kNoiseTableMaxEntries)
-        const uint32_t row = (uint32_t)d.nx, slab = mul24((uint32_t)d.nx, (uint32_t)d.ny);
-        const uint32_t i0 = mad24(mad24((uint32_t)iz, (uint32_t)d.ny, (uint32_t)iy), row, (uint32_t)ix);
-        const char* base = reinterpret_cast<const char*>(d.data);
-        const float* q00 = reinterpret_cast<const float*>(base + (i0 << 2));
-        const float* q01 = reinterpret_cast<const float*>(base + ((i0 + row) << 2));
-        const float* q10 = reinterpret_cast<const float*>(base + ((i0 + slab) << 2));
-        const float* q11 = reinterpret_cast<const float*>(base + ((i0 + slab + row) << 2));
-        float a = q00[0], b = q00[1], c = q01[0], d_ = q01[1];
-        float e = q10[0], f = q10[1], g = q11[0], h = q11[1];
-#ifdef WR_DEV
-        WR_DBG_LEVEL(d.dbg_level, 0);
+    NoiseTable d = t;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (every field now, in scalar registers: left alone, the compiler fetches the fields of the
+    // box behind the test that follows and waits a second time)
+    // (not the pointer: one that has been through an asm statement is no longer known to be global memory)
+    asm volatile("" : "+s"(d.lox), "+s"(d.loy), "+s"(d.loz), "+s"(d.nx), "+s"(d.ny), "+s"(d.nz));
 #endif
-        return mixf(mixf(mixf(a, b, sx), mixf(c, d_, sx), sy), mixf(mixf(e, f, sx), mixf(g, h, sx), sy), sz);
+    if (d.data != nullptr) {  // (the same in every lane: a level without a table skips the index arithmetic)
+        // |u| < 2^24 here (the caller bounds |p|), so the conversions are exact
+        const int ix = (int)ux - d.lox, iy = (int)uy - d.loy, iz = (int)uz - d.loz;
+        const bool inside = ((unsigned)ix < (unsigned)(d.nx - 1)) & ((unsigned)iy < (unsigned)(d.ny - 1)) & ((unsigned)iz < (unsigned)(d.nz - 1));
+        if (inside) {
+            float sx = smooth01(p.x - ux), sy = smooth01(p.y - uy), sz = smooth01(p.z - uz);
+            // inside the box every index, dimension and product below is under 2^24 (kNoiseTableMaxEntries)
+            const uint32_t row = (uint32_t)d.nx, slab = mul24((uint32_t)d.nx, (uint32_t)d.ny);
+            const uint32_t i0 = mad24(mad24((uint32_t)iz, (uint32_t)d.ny, (uint32_t)iy), row, (uint32_t)ix);
+            const char* base = reinterpret_cast<const char*>(d.data);
+            const float* q00 = reinterpret_cast<const float*>(base + (i0 << 2));
+            const float* q01 = reinterpret_cast<const float*>(base + ((i0 + row) << 2));
+            const float* q10 = reinterpret_cast<const float*>(base + ((i0 + slab) << 2));
+            const float* q11 = reinterpret_cast<const float*>(base + ((i0 + slab + row) << 2));
+            float a = q00[0], b = q00[1], c = q01[0], d_ = q01[1];
+            float e = q10[0], f = q10[1], g = q11[0], h = q11[1];
+#ifdef WR_DEV
+            WR_DBG_LEVEL(d.dbg_level, 0);
+#endif
+            return mixf(mixf(mixf(a, b, sx), mixf(c, d_, sx), sy), mixf(mixf(e, f, sx), mixf(g, h, sx), sy), sz);
+        }
     }
 #else
     // |u| < 2^24 here (the caller bounds |p|), so the conversions are exact
