@@ -241,6 +241,7 @@ float hc_fog_noise_tab(const float* p, float time, int cap, int* tabled_levels) 
         NoiseTable& t = nt.level[k * 8 + o];
         t.data = pool + used; t.lox = (int)l[0]; t.loy = (int)l[1]; t.loz = (int)l[2];
         t.nx = (int)n[0]; t.ny = (int)n[1]; t.nz = (int)n[2];
+        noise_table_seal(t);
         for (size_t i = 0; i < entries; ++i) {
             int ix = (int)(i % n[0]), iy = (int)((i / n[0]) % n[1]), iz = (int)(i / (n[0] * n[1]));
             pool[used + i] = lattice_hash((float)(t.lox + ix), (float)(t.loy + iy), (float)(t.loz + iz));

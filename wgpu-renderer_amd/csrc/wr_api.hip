@@ -58,9 +58,7 @@ constexpr int kShadowRasterThreads = WR_SHADOW_RASTER_THREADS;
 #endif
 constexpr size_t kNoiseLevelEntries = WR_NOISE_LEVEL_ENTRIES;  // largest hash table of one noise level
 constexpr size_t kNoisePoolEntries = WR_NOISE_POOL_ENTRIES;    // all levels together (4 bytes each, per frame in flight)
-#ifndef WR_TABLE_INDEX_64
-static_assert(kNoiseLevelEntries <= kNoiseTableMaxEntries, "value_noise_tab indexes a table with 24-bit multiplies");
-#endif
+static_assert(kNoiseLevelEntries <= kNoiseTableMaxEntries, "value_noise_tab forms a table index in f32");
 static_assert(sizeof(FrameConsts) < 3072, "FrameConsts must fit the kernel argument segment");
 
 // Work buffers of wr_render_frame_static, the entry point for callers that cannot allocate.
@@ -732,6 +730,7 @@ NoiseTables plan_noise_tables(const WrContext* ctx, const FrameRes* f, const Fra
         t.data = f->d_noise_pool + used;
         t.lox = (int)l[0]; t.loy = (int)l[1]; t.loz = (int)l[2];
         t.nx = (int)n[0]; t.ny = (int)n[1]; t.nz = (int)n[2];
+        noise_table_seal(t);
         used += (size_t)entries;
         *max_entries = std::max<uint32_t>(*max_entries, (uint32_t)entries);
     };

@@ -787,16 +787,24 @@ WR_HD float value_noise(V3 p) { return value_noise_t<true>(p); }
 // the same bits; a sample outside the table's box falls back to the direct evaluation.
 struct NoiseTable {
     const float* data;   // nullptr: level not tabled
-    int lox, loy, loz;   // lattice coordinate of entry (0,0,0)
-    int nx, ny, nz;
+    // What a lookup reads, derived from the box below by noise_table_seal.  Lattice coordinates
+    // here are integers below 2^24 in magnitude, so they, their differences and an index into
+    // at most kNoiseTableMaxEntries entries are exact in f32.
+    float flo[3];        // lox, loy, loz
+    uint32_t lim[3];     // bits of (float)(n - 1): u - lo lies in [0, n - 1) iff its bits, as an unsigned integer, are below
+    float fnx, fny;
+    uint32_t row_bytes, slab_bytes;  // 4 * nx, 4 * nx * ny
     // fbm_decided's bounds for this level's octave (set for every level, tabled or not, by
     // noise_tables_clear): a partial sum at or below the first or at or above the second decides.
     // They ride with the description, which the march fetches anyway with scalar loads.
     float decided_low, decided_high;
+    int lox, loy, loz;   // lattice coordinate of entry (0,0,0)
+    int nx, ny, nz;
 #ifdef WR_DEV
     int dbg_level, dbg_pad;  // level index, + 256 in the light-march kernel
 #endif
 };
+constexpr uint32_t kNoiseTableMaxEntries = 1u << 24;
 struct NoiseTables { NoiseTable level[16]; };  // [fbm index * 8 + octave]
 
 WR_HD float lattice_hash(float ux, float uy, float uz) {  // rand(u) of noise.wgsl:3-5 for integer u
@@ -830,54 +838,34 @@ __device__ inline void wr_dbg_box(int level, float ux, float uy, float uz) {
 #else
 #define WR_DBG_LEVEL(level, direct) ((void)0)
 #endif
-#ifndef WR_TABLE_INDEX_64
-// Entries a table may hold at most: every dimension, every product of dimensions and every
-// byte offset into a table then fit the 24-bit multiplies and 32-bit offsets of value_noise_tab.
-constexpr uint32_t kNoiseTableMaxEntries = 1u << 24;
-WR_HD uint32_t mul24(uint32_t a, uint32_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __umul24(a, b);
-#else
-    return (a & 0xFFFFFFu) * (b & 0xFFFFFFu);
-#endif
-}
-WR_HD uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {  // a * b + c for a, b below 2^24
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t r;  // (as assembly: the compiler widens the nested form to a 64-bit multiply-add)
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-#else
-    return (a & 0xFFFFFFu) * (b & 0xFFFFFFu) + c;
-#endif
-}
-#endif
 template <int GUARD>
 WR_HD float value_noise_tab(V3 p, const NoiseTable& t) {
     float ux = floorf(p.x), uy = floorf(p.y), uz = floorf(p.z);
-#ifndef WR_TABLE_INDEX_64
     // The level's description, fetched in one piece (one scalar load and one wait on the device,
     // where a field fetched inside each nested test was a wait per field).
     NoiseTable d = t;
 #if defined(__HIP_DEVICE_COMPILE__)
     // (every field now, in scalar registers: left alone, the compiler fetches the fields of the
-    // box behind the test that follows and waits a second time)
-    // (not the pointer: one that has been through an asm statement is no longer known to be global memory)
-    asm volatile("" : "+s"(d.lox), "+s"(d.loy), "+s"(d.loz), "+s"(d.nx), "+s"(d.ny), "+s"(d.nz));
+    // box behind the test that follows and waits a second time.  Not the pointer: one that has
+    // been through an asm statement is no longer known to be global memory.)
+    asm volatile("" : "+s"(d.flo[0]), "+s"(d.flo[1]), "+s"(d.flo[2]), "+s"(d.lim[0]), "+s"(d.lim[1]), "+s"(d.lim[2]),
+                      "+s"(d.fnx), "+s"(d.fny), "+s"(d.row_bytes), "+s"(d.slab_bytes));
 #endif
     if (d.data != nullptr) {  // (the same in every lane: a level without a table skips the index arithmetic)
-        // |u| < 2^24 here (the caller bounds |p|), so the conversions are exact
-        const int ix = (int)ux - d.lox, iy = (int)uy - d.loy, iz = (int)uz - d.loz;
-        const bool inside = ((unsigned)ix < (unsigned)(d.nx - 1)) & ((unsigned)iy < (unsigned)(d.ny - 1)) & ((unsigned)iz < (unsigned)(d.nz - 1));
+        // position in the box, exact; a negative difference has its sign bit set and fails the
+        // unsigned comparison like one that is too large.  (-0 - 0 = -0 fails it too: the direct
+        // evaluation below gives the same bits.)
+        const float fx = ux - d.flo[0], fy = uy - d.flo[1], fz = uz - d.flo[2];
+        const bool inside = ((int)(f2u(fx) < d.lim[0]) & (int)(f2u(fy) < d.lim[1]) & (int)(f2u(fz) < d.lim[2])) != 0;  // (no short circuit: one branch)
         if (inside) {
             float sx = smooth01(p.x - ux), sy = smooth01(p.y - uy), sz = smooth01(p.z - uz);
-            // inside the box every index, dimension and product below is under 2^24 (kNoiseTableMaxEntries)
-            const uint32_t row = (uint32_t)d.nx, slab = mul24((uint32_t)d.nx, (uint32_t)d.ny);
-            const uint32_t i0 = mad24(mad24((uint32_t)iz, (uint32_t)d.ny, (uint32_t)iy), row, (uint32_t)ix);
+            // (z * ny + y) * nx + x: every product and sum an integer below 2^24, so exact, fused or not
+            const uint32_t o00 = (uint32_t)fmaf(fmaf(fz, d.fny, fy), d.fnx, fx) << 2;
             const char* base = reinterpret_cast<const char*>(d.data);
-            const float* q00 = reinterpret_cast<const float*>(base + (i0 << 2));
-            const float* q01 = reinterpret_cast<const float*>(base + ((i0 + row) << 2));
-            const float* q10 = reinterpret_cast<const float*>(base + ((i0 + slab) << 2));
-            const float* q11 = reinterpret_cast<const float*>(base + ((i0 + slab + row) << 2));
+            const float* q00 = reinterpret_cast<const float*>(base + o00);
+            const float* q01 = reinterpret_cast<const float*>(base + (o00 + d.row_bytes));
+            const float* q10 = reinterpret_cast<const float*>(base + (o00 + d.slab_bytes));
+            const float* q11 = reinterpret_cast<const float*>(base + (o00 + d.slab_bytes + d.row_bytes));
             float a = q00[0], b = q00[1], c = q01[0], d_ = q01[1];
             float e = q10[0], f = q10[1], g = q11[0], h = q11[1];
 #ifdef WR_DEV
@@ -886,22 +874,6 @@ WR_HD float value_noise_tab(V3 p, const NoiseTable& t) {
             return mixf(mixf(mixf(a, b, sx), mixf(c, d_, sx), sy), mixf(mixf(e, f, sx), mixf(g, h, sx), sy), sz);
         }
     }
-#else
-    // |u| < 2^24 here (the caller bounds |p|), so the conversions are exact
-    int ix = (int)ux - t.lox, iy = (int)uy - t.loy, iz = (int)uz - t.loz;
-    if (t.data != nullptr && (unsigned)ix < (unsigned)(t.nx - 1) && (unsigned)iy < (unsigned)(t.ny - 1) &&
-        (unsigned)iz < (unsigned)(t.nz - 1)) {
-        float sx = smooth01(p.x - ux), sy = smooth01(p.y - uy), sz = smooth01(p.z - uz);
-        const float* q = t.data + ((size_t)iz * t.ny + iy) * t.nx + ix;
-        const size_t sy_ = (size_t)t.nx, sz_ = (size_t)t.nx * t.ny;
-        float a = q[0], b = q[1], c = q[sy_], d = q[sy_ + 1];
-        float e = q[sz_], f = q[sz_ + 1], g = q[sz_ + sy_], h = q[sz_ + sy_ + 1];
-#ifdef WR_DEV
-        WR_DBG_LEVEL(t.dbg_level, 0);
-#endif
-        return mixf(mixf(mixf(a, b, sx), mixf(c, d, sx), sy), mixf(mixf(e, f, sx), mixf(g, h, sx), sy), sz);
-    }
-#endif
 #ifdef WR_DEV
     WR_DBG_LEVEL(t.dbg_level, 1);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -934,6 +906,16 @@ WR_HD bool fbm_decided(float ret, int i) {
     const float rest = WR_FBM_REST(i);
     return fbm_decided_between(ret, -rest, 1.0f + rest);
 }
+// The lookup's fields of a level whose box (lo, n) has been set.
+WR_HD void noise_table_seal(NoiseTable& t) {
+    t.flo[0] = (float)t.lox; t.flo[1] = (float)t.loy; t.flo[2] = (float)t.loz;
+    t.lim[0] = t.nx > 1 ? f2u((float)(t.nx - 1)) : 0u;
+    t.lim[1] = t.ny > 1 ? f2u((float)(t.ny - 1)) : 0u;
+    t.lim[2] = t.nz > 1 ? f2u((float)(t.nz - 1)) : 0u;
+    t.fnx = (float)t.nx; t.fny = (float)t.ny;
+    t.row_bytes = 4u * (uint32_t)t.nx;
+    t.slab_bytes = 4u * (uint32_t)t.nx * (uint32_t)t.ny;
+}
 // No level tabled; every level's bounds as fbm_decided computes them.
 WR_HD void noise_tables_clear(NoiseTables& nt) {
     for (int l = 0; l < 16; ++l) {
@@ -941,6 +923,7 @@ WR_HD void noise_tables_clear(NoiseTables& nt) {
         t.data = nullptr;
         t.lox = t.loy = t.loz = 0;
         t.nx = t.ny = t.nz = 0;
+        noise_table_seal(t);
         const float rest = WR_FBM_REST(l & 7);
         t.decided_low = -rest;
         t.decided_high = 1.0f + rest;
