@@ -11,6 +11,8 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
+    # correctness tests run several frames in flight on whatever queue count the box exports
+    config.addinivalue_line("filterwarnings", "ignore:frames_in_flight=.*GPU_MAX_HW_QUEUES:RuntimeWarning")
 
 
 def _gpu_present():

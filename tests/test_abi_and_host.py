@@ -527,3 +527,17 @@ def test_native_jpeg_decode_survives_corrupt_streams():
                 assert px.ndim == 3 and px.shape[2] == 4
             except abi.WrError as e:
                 assert e.code in (abi.WR_ERR_INVALID_ARGUMENT, abi.WR_ERR_UNSUPPORTED)
+
+
+def test_python_host_says_when_hardware_queues_are_too_few(monkeypatch):
+    """Several frames in flight need a HIP hardware queue per stream (three per frame in flight
+    and one more); HIP's default is four per process."""
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    assert abi.hardware_queues_short_of(1) is None
+    assert abi.hardware_queues_short_of(2) == 4 and abi.hardware_queues_short_of(4) == 4
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+    assert abi.hardware_queues_short_of(2) is None and abi.hardware_queues_short_of(4) == 8
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "16")
+    assert abi.hardware_queues_short_of(4) is None
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "many")
+    assert abi.hardware_queues_short_of(3) == 4

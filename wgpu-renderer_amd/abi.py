@@ -333,6 +333,21 @@ class Glb:
             pass
 
 
+def hardware_queues_short_of(frames_in_flight: int):
+    """HIP gives a process GPU_MAX_HW_QUEUES hardware queues (4 unless the environment says
+    otherwise, read at the first HIP call).  A context keeps three streams per frame in flight and
+    one more; with fewer queues than that, frames in flight beyond one share queues and run slower
+    than one frame at a time.  Returns the queue count if it is too small for `frames_in_flight`,
+    else None."""
+    if frames_in_flight <= 1:
+        return None
+    try:
+        queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "") or 4)
+    except ValueError:
+        queues = 4
+    return queues if queues < 3 * frames_in_flight + 1 else None
+
+
 class Renderer:
     """One wr context (one GPU, one stream): the object a host keeps where the reference
     keeps its wgpu Device/Queue/pipelines (state.rs:30-66)."""
@@ -341,6 +356,12 @@ class Renderer:
                  tile_rank: int = 0, tile_world: int = 1, stream: Optional[int] = None, frames_in_flight: int = 1,
                  color_format: int = 0):
         self.lib = load_library()
+        queues = hardware_queues_short_of(frames_in_flight)
+        if queues is not None:
+            import warnings
+            warnings.warn(f"frames_in_flight={frames_in_flight} with GPU_MAX_HW_QUEUES={queues}: streams will share hardware queues and "
+                          f"frames in flight will run slower than one at a time; export GPU_MAX_HW_QUEUES=16 before the first HIP call",
+                          RuntimeWarning, stacklevel=2)
         cfg = Config(width, height, shadow_map_size, color_format, device, tile_rank, tile_world, stream, frames_in_flight, 0)
         h = _P()
         rc = self.lib.wr_create(C.byref(cfg), C.byref(h))
