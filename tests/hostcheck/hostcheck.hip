@@ -83,6 +83,13 @@ __global__ void k_hc_noise(const float* p, int n, float time, float drift_z, flo
     out[3 * i + 1] = fbm(q * 0.05f);
     out[3 * i + 2] = fog_noise(fc, q);
 }
+__global__ void k_hc_noise_tab(const float* p, int n, FrameConsts fc, NoiseTables nt, float* out_tab, float* out_direct) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const V3 q = v3(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
+    out_tab[i] = fog_noise_tab(fc, nt, q);
+    out_direct[i] = fog_noise(fc, q);
+}
 // 17 floats in (n, l, v, h, albedo, roughness, metalness), 3 out
 __global__ void k_hc_brdf(const float* in, int n, float* out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -220,24 +227,23 @@ float hc_fog_noise(const float* p, float time) {
     fc.time = time; fc.drift_xy = time * 0.2f; fc.drift_z = wr_sin(time * 0.1f) * 0.5f;
     return fog_noise(fc, v3(p[0], p[1], p[2]));
 }
-// fog_noise through hash tables built on the host for a box around p (every level whose
-// lattice box has at most `cap` entries), to compare with the direct evaluation.
-float hc_fog_noise_tab(const float* p, float time, int cap, int* tabled_levels) {
-    FrameConsts fc; memset(&fc, 0, sizeof(fc));
-    fc.time = time; fc.drift_xy = time * 0.2f; fc.drift_z = wr_sin(time * 0.1f) * 0.5f;
-    NoiseTables nt; memset(&nt, 0, sizeof(nt)); noise_tables_clear(nt);
-    static float pool[1 << 16];
+// Hash tables built on the host over the world-space box [lo, hi] (every level whose lattice box
+// has at most `cap` entries), in `pool`.  Returns the number of tabled levels.
+static int build_box_tables(const FrameConsts& fc, const float* lo, const float* hi, int cap, NoiseTables& nt, float* pool,
+                            size_t pool_entries, size_t* used_out) {
+    memset(&nt, 0, sizeof(nt));
+    noise_tables_clear(nt);
     size_t used = 0; int nlev = 0;
     const double drift[3] = {fc.drift_xy, fc.drift_xy, fc.drift_z};
     for (int k = 0; k < 2; ++k) for (int o = 0; o < 8; ++o) {
         double s = k == 0 ? 0.01 : 0.05, m = (double)(1 << o);
         long l[3], n[3];
         for (int r = 0; r < 3; ++r) {
-            double a = ((p[r] - 3.0) * s + drift[r]) * m, b = ((p[r] + 3.0) * s + drift[r]) * m;
+            double a = (lo[r] * s + drift[r]) * m, b = (hi[r] * s + drift[r]) * m;
             l[r] = (long)floor(a) - 1; n[r] = (long)floor(b) + 2 - l[r] + 1;
         }
         size_t entries = (size_t)(n[0] * n[1] * n[2]);
-        if ((int)entries > cap || used + entries > sizeof(pool) / 4) continue;
+        if ((long)entries > (long)cap || used + entries > pool_entries) continue;
         NoiseTable& t = nt.level[k * 8 + o];
         t.data = pool + used; t.lox = (int)l[0]; t.loy = (int)l[1]; t.loz = (int)l[2];
         t.nx = (int)n[0]; t.ny = (int)n[1]; t.nz = (int)n[2];
@@ -248,8 +254,46 @@ float hc_fog_noise_tab(const float* p, float time, int cap, int* tabled_levels) 
         }
         used += entries; ++nlev;
     }
-    *tabled_levels = nlev;
+    if (used_out) *used_out = used;
+    return nlev;
+}
+static FrameConsts noise_consts(float time) {
+    FrameConsts fc; memset(&fc, 0, sizeof(fc));
+    fc.time = time; fc.drift_xy = time * 0.2f; fc.drift_z = wr_sin(time * 0.1f) * 0.5f;
+    return fc;
+}
+// fog_noise through hash tables built on the host for a box around p, to compare with the direct
+// evaluation (host build of the lookup).
+float hc_fog_noise_tab(const float* p, float time, int cap, int* tabled_levels) {
+    const FrameConsts fc = noise_consts(time);
+    NoiseTables nt;
+    static float pool[1 << 16];
+    const float lo[3] = {p[0] - 3.0f, p[1] - 3.0f, p[2] - 3.0f}, hi[3] = {p[0] + 3.0f, p[1] + 3.0f, p[2] + 3.0f};
+    *tabled_levels = build_box_tables(fc, lo, hi, cap, nt, pool, sizeof(pool) / 4, nullptr);
     return fog_noise_tab(fc, nt, v3(p[0], p[1], p[2]));
+}
+// The same on the device: tables over the box [lo, hi] built on the host and copied over, then
+// fog_noise_tab and fog_noise of n points (inside the box and outside it) by a kernel.
+int hc_dev_fog_noise_tab(const float* pts, int n, const float* lo, const float* hi, float time, int cap, float* out_tab,
+                         float* out_direct, int* tabled_levels) {
+    const FrameConsts fc = noise_consts(time);
+    NoiseTables nt;
+    const size_t pool_entries = (size_t)1 << 22;
+    float* pool = new float[pool_entries];
+    size_t used = 0;
+    *tabled_levels = build_box_tables(fc, lo, hi, cap, nt, pool, pool_entries, &used);
+    DevBufs b;
+    float* dpool = b.make<float>(used ? used : 1, pool);
+    for (int l = 0; l < 16; ++l)
+        if (nt.level[l].data) nt.level[l].data = dpool + (nt.level[l].data - pool);
+    delete[] pool;
+    float* dp = b.make<float>(3 * (size_t)n, pts);
+    float* dt = b.make<float>((size_t)n);
+    float* dd = b.make<float>((size_t)n);
+    if (b.err == hipSuccess) k_hc_noise_tab<<<(n + 255) / 256, 256>>>(dp, n, fc, nt, dt, dd);
+    b.fetch(out_tab, dt, (size_t)n);
+    b.fetch(out_direct, dd, (size_t)n);
+    return (int)b.err;
 }
 void hc_brdf(const float* n, const float* l, const float* v, const float* h, const float* a, float rough, float metal, float* out) {
     V3 r = brdf(v3(n[0], n[1], n[2]), v3(l[0], l[1], l[2]), v3(v[0], v[1], v[2]), v3(h[0], h[1], h[2]), v3(a[0], a[1], a[2]), rough, metal);

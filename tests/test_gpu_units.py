@@ -36,6 +36,7 @@ def H():
     h.hc_dev_srgb_encode_mismatches.restype = C.c_longlong
     h.hc_dev_blend_pack.argtypes = [up, fp, C.POINTER(C.c_int), C.c_int, up]
     h.hc_dev_setup_triangles.argtypes = [fp, C.c_int, C.c_uint32, C.c_uint32, C.c_int, up, C.POINTER(C.c_int)]
+    h.hc_dev_fog_noise_tab.argtypes = [fp, C.c_int, fp, fp, C.c_float, C.c_int, fp, fp, C.POINTER(C.c_int)]
     h.hc_blend_pack.restype = C.c_uint
     h.hc_blend_pack.argtypes = [C.c_uint, fp, C.c_int]
     return h
@@ -183,3 +184,31 @@ def test_triangle_setup_on_the_device(H, L):
             assert np.array_equal(A, out[i, :na]), (i, shadow)
             total += na
     assert total > 4000
+
+
+def test_noise_through_tables_on_the_device(H, L):
+    """fog_noise_tab as the kernels use it, with tables over a box of the fog volume built by the
+    host: points inside the box (table hits in the levels that fit the budget), on its faces and
+    on lattice planes, around it and far outside (every lane of a wavefront may take another way
+    through the lookup), against the direct evaluation on the device and the oracle."""
+    rng = np.random.default_rng(26)
+    for time, centre, half, cap in ((2.0, (-200.0, 40.0, 100.0), 40.0, 1 << 20), (0.0, (0.0, 0.0, 0.0), 25.0, 1 << 18), (7.5, (640.0, -30.0, -350.0), 12.0, 1 << 16)):
+        c = np.array(centre)
+        lo, hi = (c - half).astype(np.float32), (c + half).astype(np.float32)
+        inside = rng.uniform(lo, hi, (6000, 3))
+        around = rng.uniform(c - 1.5 * half, c + 1.5 * half, (3000, 3))
+        far = rng.uniform(-3000, 3000, (500, 3))
+        planes = inside[:800].copy()
+        planes[:, 0] = np.round(planes[:, 0] / 6.25) * 6.25   # on lattice planes of the coarse octaves (drift aside)
+        faces = inside[:600].copy()
+        faces[:200, 0], faces[200:400, 1], faces[400:, 2] = lo[0], hi[1], lo[2]
+        special = np.array([centre, lo, hi, [0, 0, 0], [-0.0, -0.0, -0.0]])
+        pts = np.ascontiguousarray(np.concatenate([inside, around, far, planes, faces, special]).astype(np.float32))
+        n = len(pts)
+        tab, direct = np.empty(n, np.float32), np.empty(n, np.float32)
+        levels = C.c_int(0)
+        assert H.hc_dev_fog_noise_tab(ptr(pts), n, ptr(lo), ptr(hi), time, cap, ptr(tab), ptr(direct), C.byref(levels)) == 0
+        assert levels.value >= 5, levels.value
+        assert same_bits(tab, direct)
+        want = np.array([L.wro_fog_noise(f3(p), time) for p in pts], np.float32)
+        assert same_bits(tab, want)

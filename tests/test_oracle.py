@@ -367,3 +367,26 @@ def test_product_triangle_setup_is_bit_identical_to_oracle(hc):
             assert np.array_equal(A, B)
             total += na
     assert total > 2000
+
+
+def test_product_noise_through_tables_equals_the_direct_evaluation(hc):
+    """Host build of the table lookup (value_noise_tab: position in the box in f32, box test on
+    the bits of u - lo, index by fused multiply-adds): fog_noise through tables built around the
+    point equals the direct evaluation and the oracle bit for bit, also where a coordinate sits on
+    a lattice plane (every octave's floor is then the coordinate itself), at zero and minus zero,
+    and at negative coordinates."""
+    hc.hc_fog_noise_tab.restype = C.c_float
+    hc.hc_fog_noise_tab.argtypes = [C.POINTER(C.c_float), C.c_float, C.c_int, C.POINTER(C.c_int)]
+    rng = np.random.default_rng(31)
+    pts = [rng.uniform(-1500, 1500, 3) for _ in range(300)]
+    pts += [np.array(v, np.float64) for v in ([0, 0, 0], [-0.0, -0.0, -0.0], [100, 200, -300], [-100, 20, 40], [12.5, -6.25, 3.125],
+                                              [1e-30, -1e-30, 0.0], [-700, 50, 599.99], [-0.78125, 0.390625, -0.1953125])]
+    hits = 0
+    for time in (0.0, 2.0, 7.5):
+        for p in pts:
+            levels = C.c_int(0)
+            got = hc.hc_fog_noise_tab(f3(np.asarray(p, np.float32)), time, 4096, C.byref(levels))
+            want = L.wro_fog_noise(f3(np.asarray(p, np.float32)), time)
+            assert bits(got) == bits(want), (p, time)
+            hits += levels.value
+    assert hits > 8 * len(pts)  # most levels of most points were read from tables
